@@ -1,0 +1,481 @@
+"""CPU ORACLE (test infrastructure, NOT product code).
+
+Pure-torch restatement of TriplaneTurbo's differentiable triplane volume
+renderer hot path.  It exists so that the HIP path in ``triplaneturbo_amd`` can
+be checked; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import it.  The product path never routes through it.
+
+Parity status
+-------------
+* plane sampling, MLP decode, first-order normals: PINNED against the
+  importable reference functions (``tests/golden/make_golden.py`` imports
+  ``/root/reference/triplaneturbo_executable`` in the build container and dumps
+  ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` replays them).
+* second-order terms: checked by fp64 ``gradcheck``/``gradgradcheck`` of this
+  restatement (the reference's own double backward is CUDA-only).
+* ray marching (nerfacc v0.5.2 ``render_weight_from_alpha`` /
+  ``accumulate_along_rays`` / ``importance_sampling``): nerfacc is an
+  un-vendored third-party dependency (requirements.txt:5) and the reference
+  has no tests for it => **parity unpinned** at that boundary; the restatement
+  follows nerfacc's published semantics and the reference's call sites.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).  All functions are dtype-generic (fp32 follows the
+reference's op order; fp64 is used as the "exact" arbiter).
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------
+# plane re-orientation, projection, bilinear sampling
+# --------------------------------------------------------------------------
+def rotate_planes_v1(space_cache: Tensor) -> Tensor:
+    """custom/triplaneturbo/models/geometry/few_step_triplane_dual_stable_diffusion.py:212-225
+
+    space_cache (B, 6, C, H, W) -> re-oriented copy.  Planes 0,3: transpose;
+    planes 1,4: rot180; planes 2,5: rot90 clockwise.
+    """
+    out = torch.zeros_like(space_cache)
+    out[:, 0::3] = torch.transpose(space_cache[:, 0::3], 3, 4)
+    out[:, 1::3] = torch.rot90(space_cache[:, 1::3], k=2, dims=(3, 4))
+    out[:, 2::3] = torch.rot90(space_cache[:, 2::3], k=-1, dims=(3, 4))
+    return out
+
+
+def project_onto_planes(coordinates: Tensor) -> Tensor:
+    """custom/triplaneturbo/models/geometry/utils.py:46-63,111-125
+
+    The reference multiplies by inverses of three permutation matrices; the
+    products are exact, so the projection is a component selection:
+    plane0 -> (x, y), plane1 -> (x, z), plane2 -> (z, y).
+    coordinates (N, M, 3) -> (N, 3, M, 2)
+    """
+    x, y, z = coordinates.unbind(-1)
+    return torch.stack(
+        [torch.stack([x, y], -1), torch.stack([x, z], -1), torch.stack([z, y], -1)],
+        dim=1,
+    )
+
+
+def bilinear_corners(grid: Tensor, H: int, W: int):
+    """ATen GridSampler (align_corners=False, zeros padding) index math,
+    aten/src/ATen/native/cuda/GridSampler.cuh:23-31 and
+    gridsample_cuda.cu:87-129 (same formulas).
+
+    grid (..., 2) with [...,0] -> W axis.  Returns a list of 4 corners
+    (iy, ix, weight, in_bounds) in the order nw, ne, sw, se, plus (ix, iy).
+    """
+    gx, gy = grid[..., 0], grid[..., 1]
+    ix = ((gx + 1) * W - 1) / 2
+    iy = ((gy + 1) * H - 1) / 2
+    ix_nw = torch.floor(ix)
+    iy_nw = torch.floor(iy)
+    ix_ne, iy_ne = ix_nw + 1, iy_nw
+    ix_sw, iy_sw = ix_nw, iy_nw + 1
+    ix_se, iy_se = ix_nw + 1, iy_nw + 1
+    nw = (ix_se - ix) * (iy_se - iy)
+    ne = (ix - ix_sw) * (iy_sw - iy)
+    sw = (ix_ne - ix) * (iy - iy_ne)
+    se = (ix - ix_nw) * (iy - iy_nw)
+    corners = []
+    for cx, cy, w in ((ix_nw, iy_nw, nw), (ix_ne, iy_ne, ne), (ix_sw, iy_sw, sw), (ix_se, iy_se, se)):
+        inb = (cx >= 0) & (cx <= W - 1) & (cy >= 0) & (cy <= H - 1)
+        corners.append((cy, cx, w, inb))
+    return corners
+
+
+def grid_sample_gather(inp: Tensor, grid: Tensor) -> Tensor:
+    """Gather-based restatement of F.grid_sample(mode='bilinear',
+    padding_mode='zeros', align_corners=False)
+    (custom/triplaneturbo/models/geometry/utils.py:21-24).
+
+    Built from differentiable indexing so that autograd provides first AND
+    second order derivatives on CPU (stock torch has no double backward for
+    aten::grid_sampler_2d_backward; the reference needs its CUDA extension
+    gridsample_cuda.cu for that).
+
+    inp (N, C, H, W), grid (N, M, 2) -> (N, M, C)
+    """
+    N, C, H, W = inp.shape
+    flat = inp.permute(0, 2, 3, 1).reshape(N, H * W, C)
+    out = None
+    for cy, cx, w, inb in bilinear_corners(grid, H, W):
+        idx = (cy.clamp(0, H - 1) * W + cx.clamp(0, W - 1)).long()  # (N, M)
+        val = torch.gather(flat, 1, idx[..., None].expand(-1, -1, C))
+        val = val * inb[..., None].to(inp.dtype)
+        term = val * w[..., None]
+        out = term if out is None else out + term
+    return out
+
+
+def sample_from_planes(plane_features: Tensor, coordinates: Tensor, interpolate_feat: str,
+                       box_warp: float = 2.0) -> Tensor:
+    """custom/triplaneturbo/models/geometry/utils.py:127-145 (v1 = sum, v2 = concat).
+
+    plane_features (N, 3, C, H, W) (already re-oriented), coordinates (N, M, 3).
+    """
+    N, n_planes, C, H, W = plane_features.shape
+    M = coordinates.shape[1]
+    coordinates = (2 / box_warp) * coordinates
+    proj = project_onto_planes(coordinates).reshape(N * n_planes, M, 2)
+    feats = grid_sample_gather(plane_features.reshape(N * n_planes, C, H, W), proj)
+    feats = feats.reshape(N, n_planes, M, C)
+    if interpolate_feat in (None, "v1"):
+        return feats.sum(dim=1)
+    elif interpolate_feat == "v2":
+        return feats.permute(0, 2, 1, 3).reshape(N, M, n_planes * C)
+    raise ValueError(interpolate_feat)
+
+
+# --------------------------------------------------------------------------
+# MLP, activations
+# --------------------------------------------------------------------------
+def vanilla_mlp(x: Tensor, weights: Sequence[Tensor]) -> Tensor:
+    """threestudio/models/networks.py:67-104 -- Linear(bias=False)+ReLU, no output activation."""
+    for i, w in enumerate(weights):
+        x = F.linear(x, w)
+        if i + 1 < len(weights):
+            x = torch.relu(x)
+    return x
+
+
+def sigmoid_mipnerf(x: Tensor) -> Tensor:
+    """threestudio/utils/ops.py:118-119"""
+    return torch.sigmoid(x) * (1 + 2 * 0.001) - 0.001
+
+
+def scale_tensor(dat: Tensor, inp_scale, tgt_scale) -> Tensor:
+    """threestudio/utils/ops.py:27-38"""
+    dat = (dat - inp_scale[0]) / (inp_scale[1] - inp_scale[0])
+    dat = dat * (tgt_scale[1] - tgt_scale[0]) + tgt_scale[0]
+    return dat
+
+
+# --------------------------------------------------------------------------
+# geometry decode (per point)
+# --------------------------------------------------------------------------
+def geometry_forward(points: Tensor, space_cache: Tensor, sdf_weights: Sequence[Tensor],
+                     feat_weights: Sequence[Tensor], radius: float = 1.0,
+                     sdf_bias_radius: float = 0.5, output_normal: bool = True,
+                     create_graph: bool = False) -> Dict[str, Tensor]:
+    """few_step_triplane_dual_stable_diffusion.py:273-351 (+ :131-154, :198-271).
+
+    points (B, N, 3) in world units; space_cache (B, 6, C, H, W) as produced by
+    the generator (NOT yet re-oriented).  Returns tensors shaped (B*N, .).
+    """
+    B, N, _ = points.shape
+    if output_normal and not points.requires_grad:
+        points = points.detach().requires_grad_(True)  # few_step...:283-286
+    with (torch.enable_grad() if output_normal else contextlib.nullcontext()):
+        points_unscaled = points
+        pts = scale_tensor(points, (-radius, radius), (-1, 1))  # contract_to_unisphere_custom, utils.py:31-43
+        rot = rotate_planes_v1(space_cache)
+        enc_geo = sample_from_planes(rot[:, 0:3], pts, "v1")
+        enc_tex = sample_from_planes(rot[:, 3:6], pts, "v2")
+        sdf_orig = vanilla_mlp(enc_geo, sdf_weights).view(B, N, 1)
+        sdf_bias = (points_unscaled ** 2).sum(dim=-1, keepdim=True).sqrt() - sdf_bias_radius
+        sdf = sdf_orig + sdf_bias
+        features = vanilla_mlp(enc_tex, feat_weights).view(B, N, -1)
+        out = {
+            "sdf": sdf.reshape(B * N, 1),
+            "sdf_orig": sdf_orig.reshape(B * N, 1),
+            "features": features.reshape(B * N, -1),
+            "enc_geo": enc_geo.reshape(B * N, -1),
+            "enc_tex": enc_tex.reshape(B * N, -1),
+        }
+        if output_normal:
+            sdf_grad = torch.autograd.grad(sdf, points_unscaled, grad_outputs=torch.ones_like(sdf),
+                                           create_graph=create_graph)[0]
+            normal = F.normalize(sdf_grad, dim=-1)
+            if not create_graph:
+                sdf_grad, normal = sdf_grad.detach(), normal.detach()
+            out.update(normal=normal.reshape(B * N, 3), shading_normal=normal.reshape(B * N, 3),
+                       sdf_grad=sdf_grad.reshape(B * N, 3))
+    return out
+
+
+# --------------------------------------------------------------------------
+# NeuS alpha + ray marching
+# --------------------------------------------------------------------------
+def get_alpha(sdf: Tensor, normal: Tensor, dirs: Tensor, dists: Tensor, inv_std: float,
+              cos_anneal_ratio: float = 1.0) -> Tensor:
+    """threestudio/models/renderers/neus_volume_renderer.py:93-117 (use_volsdf=False)."""
+    true_cos = (dirs * normal).sum(-1, keepdim=True)
+    iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio)
+                 + F.relu(-true_cos) * cos_anneal_ratio)
+    estimated_next_sdf = sdf + iter_cos * dists * 0.5
+    estimated_prev_sdf = sdf - iter_cos * dists * 0.5
+    prev_cdf = torch.sigmoid(estimated_prev_sdf * inv_std)
+    next_cdf = torch.sigmoid(estimated_next_sdf * inv_std)
+    p = prev_cdf - next_cdf
+    c = prev_cdf
+    return ((p + 1e-5) / (c + 1e-5)).clip(0.0, 1.0)
+
+
+def proposal_density(sdf: Tensor, inv_std: float, render_step_size: float) -> Tensor:
+    """generative_space_sdf_volume_renderer.py:288-297 (fixed-step NeuS density of the proposal pass)."""
+    estimated_next_sdf = sdf - render_step_size * 0.5
+    estimated_prev_sdf = sdf + render_step_size * 0.5
+    prev_cdf = torch.sigmoid(estimated_prev_sdf * inv_std)
+    next_cdf = torch.sigmoid(estimated_next_sdf * inv_std)
+    p = prev_cdf - next_cdf
+    c = prev_cdf
+    alpha = ((p + 1e-5) / (c + 1e-5)).clip(0.0, 1.0)
+    return alpha / render_step_size
+
+
+def render_weight_from_alpha(alpha: Tensor) -> Tuple[Tensor, Tensor]:
+    """nerfacc v0.5.2 render_weight_from_alpha on a dense (n_rays, S) layout
+    (call site generative_space_sdf_volume_renderer.py:408-412):
+    trans_i = prod_{j<i}(1-alpha_j), w_i = alpha_i * trans_i.  [parity unpinned]
+    """
+    one_minus = 1.0 - alpha
+    trans = torch.cumprod(
+        torch.cat([torch.ones_like(alpha[:, :1]), one_minus[:, :-1]], dim=1), dim=1)
+    return alpha * trans, trans
+
+
+def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Sequence[Tensor],
+           rays_o: Tensor, rays_d: Tensor, t_starts: Tensor, t_ends: Tensor,
+           bg_color: Tensor, camera_distances: Tensor, c2w: Tensor,
+           inv_std: float = 100.0, radius: float = 1.0, sdf_bias_radius: float = 0.5,
+           cos_anneal_ratio: float = 1.0, rgb_grad_shrink: float = 1.0,
+           create_graph: bool = True, training: bool = True) -> Dict[str, Tensor]:
+    """GenerativeSpaceSDFVolumeRenderer._forward for explicit sample intervals
+    (generative_space_sdf_volume_renderer.py:214-238, 326-546).
+
+    space_cache (P, 6, C, H, W); rays_o/rays_d (B, Hh, Ww, 3) with B = P*n_view
+    (view b uses prompt b // n_view, = the repeat_interleave of :120-143);
+    t_starts/t_ends (B*Hh*Ww, S); bg_color (3,) or (B*Hh*Ww, 3) or (B,Hh,Ww,3).
+    """
+    B, Hh, Ww, _ = rays_o.shape
+    P = space_cache.shape[0]
+    n_view = B // P
+    n_rays = B * Hh * Ww
+    S = t_starts.shape[1]
+    ro = rays_o.reshape(-1, 3)
+    rd = rays_d.reshape(-1, 3)
+    cache = space_cache.repeat_interleave(n_view, dim=0) if n_view > 1 else space_cache
+
+    # :333-339
+    t_positions = ((t_starts + t_ends) / 2.0).reshape(-1, 1)
+    t_intervals = (t_ends - t_starts).reshape(-1, 1)
+    ray_indices = torch.arange(n_rays).unsqueeze(-1).expand(-1, S).reshape(-1)
+    t_origins = ro[ray_indices]
+    t_dirs = rd[ray_indices]
+    positions = t_origins + t_dirs * t_positions
+
+    geo = geometry_forward(positions.reshape(B, -1, 3), cache, sdf_weights, feat_weights,
+                           radius=radius, sdf_bias_radius=sdf_bias_radius,
+                           output_normal=True, create_graph=create_graph)
+    rgb_fg_all = sigmoid_mipnerf(geo["features"])  # no_material.py:41-54
+    if rgb_grad_shrink != 1.0:  # :397-400
+        rgb_fg_all = rgb_grad_shrink * rgb_fg_all + (1.0 - rgb_grad_shrink) * rgb_fg_all.detach()
+
+    alpha = get_alpha(geo["sdf"], geo["normal"], t_dirs, t_intervals, inv_std, cos_anneal_ratio)
+    weights2d, trans2d = render_weight_from_alpha(alpha.reshape(n_rays, S))
+    weights = weights2d.reshape(-1, 1)
+
+    def accumulate(values: Optional[Tensor]) -> Tensor:
+        # nerfacc.accumulate_along_rays (call sites :414-431, :467-472)
+        src = weights if values is None else weights * values
+        return src.reshape(n_rays, S, -1).sum(dim=1)
+
+    opacity = accumulate(None)
+    depth = accumulate(t_positions)
+    comp_rgb_fg = accumulate(rgb_fg_all)
+    t_depth = depth[ray_indices]
+    z_variance = accumulate((t_positions - t_depth) ** 2)
+
+    bg = bg_color
+    if bg.ndim == 1:
+        bg = bg[None, :].expand(n_rays, -1)
+    bg = bg.reshape(n_rays, -1)
+    comp_rgb = comp_rgb_fg + bg * (1.0 - opacity)
+
+    out = {
+        "comp_rgb": comp_rgb.view(B, Hh, Ww, -1),
+        "comp_rgb_fg": comp_rgb_fg.view(B, Hh, Ww, -1),
+        "comp_rgb_bg": bg.reshape(B, Hh, Ww, -1),
+        "opacity": opacity.view(B, Hh, Ww, 1),
+        "depth": depth.view(B, Hh, Ww, 1),
+        "z_variance": z_variance.view(B, Hh, Ww, 1),
+    }
+    # :452-462 (disparity, RichDreamer convention)
+    cd = camera_distances.reshape(-1, 1, 1, 1)
+    far = cd + math.sqrt(3.0)
+    near = cd - math.sqrt(3.0)
+    disparity_tmp = out["depth"] * out["opacity"] + (1.0 - out["opacity"]) * far
+    out["disparity"] = torch.clamp((far - disparity_tmp) / (far - near), 0.0, 1.0)
+
+    # :466-505 (normal_direction == "camera")
+    comp_normal = F.normalize(accumulate(geo["normal"]), dim=-1)
+    out["comp_normal"] = comp_normal.view(B, Hh, Ww, 3)
+    bg_normal = 0.5 * torch.ones_like(comp_normal)
+    bg_normal[:, 2] = 1.0
+    bg_normal_white = torch.ones_like(comp_normal)
+    w2c = torch.inverse(c2w)
+    rot = w2c[:, :3, :3]
+    comp_normal_cam = comp_normal.view(B, -1, 3) @ rot.permute(0, 2, 1)
+    flip_x = torch.eye(3, dtype=comp_normal.dtype)
+    flip_x[0, 0] = -1
+    comp_normal_cam = (comp_normal_cam @ flip_x[None]).view(-1, 3)
+    out["comp_normal_cam_vis"] = ((comp_normal_cam + 1.0) / 2.0 * opacity + (1 - opacity) * bg_normal).view(B, Hh, Ww, 3)
+    out["comp_normal_cam_vis_white"] = ((comp_normal_cam + 1.0) / 2.0 * opacity + (1 - opacity) * bg_normal_white).view(B, Hh, Ww, 3)
+
+    if training:  # :532-545
+        out.update(weights=weights, t_points=t_positions, t_intervals=t_intervals, t_dirs=t_dirs,
+                   ray_indices=ray_indices, points=positions, alpha=alpha, trans=trans2d.reshape(-1, 1),
+                   sdf=geo["sdf"], sdf_orig=geo["sdf_orig"], features=geo["features"],
+                   normal=geo["normal"], shading_normal=geo["shading_normal"],
+                   sdf_grad=geo["sdf_grad"], inv_std=torch.tensor(inv_std))
+    return out
+
+
+# --------------------------------------------------------------------------
+# samplers
+# --------------------------------------------------------------------------
+def uniform_intervals(n_rays: int, n_samples: int, near: float, far: float, dtype=torch.float32):
+    """Level-0 of ImportanceEstimator.sampling with stratified=False
+    (threestudio/models/estimators.py:61-79, 104-118): n_samples equal
+    intervals on [near, far].  t_k = near + (far-near) * k / n_samples."""
+    s = torch.linspace(0.0, 1.0, n_samples + 1, dtype=dtype)
+    t = s * far + (1 - s) * near  # _transform_stot "uniform"
+    t = t[None, :].expand(n_rays, -1)
+    return t[:, :-1].contiguous(), t[:, 1:].contiguous()
+
+
+def importance_resample(t_edges: Tensor, cdfs: Tensor, n: int) -> Tensor:
+    """Deterministic (stratified=False) inverse-CDF placement of n+1 edges,
+    following nerfacc v0.5.2 pdf.importance_sampling semantics for a dense
+    batch: u_k = k/n (k=0..n) mapped through the piecewise-linear CDF.
+    [parity unpinned: nerfacc's exact u convention lives in its pdf.cu]
+
+    t_edges (R, K+1) increasing, cdfs (R, K+1) non-decreasing in [0,1].
+    """
+    R = t_edges.shape[0]
+    u = torch.linspace(0.0, 1.0, n + 1, dtype=t_edges.dtype)[None, :].expand(R, -1).contiguous()
+    idx = torch.searchsorted(cdfs.contiguous(), u, right=True)
+    lo = (idx - 1).clamp(0, cdfs.shape[1] - 1)
+    hi = idx.clamp(0, cdfs.shape[1] - 1)
+    c_lo, c_hi = cdfs.gather(1, lo), cdfs.gather(1, hi)
+    t_lo, t_hi = t_edges.gather(1, lo), t_edges.gather(1, hi)
+    denom = c_hi - c_lo
+    frac = torch.where(denom > 0, (u - c_lo) / torch.where(denom > 0, denom, torch.ones_like(denom)),
+                       torch.zeros_like(denom))
+    return t_lo + frac.clamp(0, 1) * (t_hi - t_lo)
+
+
+def importance_sampling(sdf_fn, n_rays: int, n_prop: int, n_fine: int, near: float, far: float,
+                        inv_std: float, render_step_size: float, dtype=torch.float32):
+    """ImportanceEstimator.sampling, one proposal level, stratified=False
+    (threestudio/models/estimators.py:22-101; prop_sigma_fn =
+    generative_space_sdf_volume_renderer.py:243-299).
+
+    sdf_fn(t_starts, t_ends) -> sdf (n_rays, n_prop) evaluated at interval mid-points.
+    Returns t_starts, t_ends (n_rays, n_prop + n_fine + 1).
+    """
+    ts, te = uniform_intervals(n_rays, n_prop, near, far, dtype)
+    t_vals = torch.cat([ts, te[:, -1:]], dim=1)
+    sdf = sdf_fn(ts, te)
+    sigma = proposal_density(sdf, inv_std, render_step_size)
+    # nerfacc.render_transmittance_from_density: exp(-exclusive_cumsum(sigma * dt))
+    sd = sigma * (te - ts)
+    excl = torch.cumsum(torch.cat([torch.zeros_like(sd[:, :1]), sd[:, :-1]], dim=1), dim=1)
+    trans = torch.exp(-excl)
+    cdfs = 1.0 - torch.cat([trans, torch.zeros_like(trans[:, :1])], dim=1)
+    t_fine = importance_resample(t_vals, cdfs, n_fine)
+    t_all, _ = torch.sort(torch.cat([t_vals, t_fine], dim=1), dim=1)
+    return t_all[:, :-1].contiguous(), t_all[:, 1:].contiguous()
+
+
+# --------------------------------------------------------------------------
+# the reference's native op: second-order grid_sample (K1)
+# --------------------------------------------------------------------------
+def grid_sample_2d_grad2(grad2_grad_input: Tensor, grad2_grad_grid: Tensor, grad_output: Tensor,
+                         inp: Tensor, grid: Tensor):
+    """Restatement of gridsample_cuda.cu:27-210 / gridsample_cuda.cpp:26-37
+    (``grad2_2d``; zeros padding, align_corners=False) obtained by
+    differentiating the restated bilinear op twice with autograd.
+
+    inp (N,C,H,W), grid (N,Ho,Wo,2), grad_output (N,C,Ho,Wo),
+    grad2_grad_input like inp, grad2_grad_grid like grid.
+    Returns (grad_grad_output, grad_input, grad_grid).
+    """
+    N, C, H, W = inp.shape
+    Ho, Wo = grid.shape[1:3]
+    inp_ = inp.detach().requires_grad_(True)
+    grid_ = grid.detach().requires_grad_(True)
+    go_ = grad_output.detach().requires_grad_(True)
+    out = grid_sample_gather(inp_, grid_.reshape(N, Ho * Wo, 2))  # (N, M, C)
+    out = out.permute(0, 2, 1).reshape(N, C, Ho, Wo)
+    g_inp, g_grid = torch.autograd.grad(out, (inp_, grid_), go_, create_graph=True)
+    scalar = (g_inp * grad2_grad_input).sum() + (g_grid * grad2_grad_grid).sum()
+    ggo, gi, gg = torch.autograd.grad(scalar, (go_, inp_, grid_), allow_unused=True)
+    gi = torch.zeros_like(inp) if gi is None else gi
+    gg = torch.zeros_like(grid) if gg is None else gg
+    return ggo, gi, gg
+
+
+# --------------------------------------------------------------------------
+# cameras (synthetic inputs; reference training distribution)
+# --------------------------------------------------------------------------
+def make_cameras(n_view: int, height: int, width: int, fovy_deg: float = 60.0,
+                 rel_distance: float = 0.9, elevation_deg: float = 15.0,
+                 azimuth_start_deg: float = 0.0, dtype=torch.float32):
+    """custom/triplaneturbo/data/*v2.py:251-359 + threestudio/utils/ops.py:194-231,301-347.
+    Returns rays_o, rays_d (n_view, H, W, 3), c2w (n_view,4,4), camera_distances (n_view,)."""
+    fovy = torch.full((n_view,), fovy_deg * math.pi / 180, dtype=dtype)
+    az = (azimuth_start_deg + 360.0 / n_view * torch.arange(n_view, dtype=dtype)) * math.pi / 180
+    el = torch.full((n_view,), elevation_deg * math.pi / 180, dtype=dtype)
+    cam_d = rel_distance / torch.tan(0.5 * fovy)
+    pos = torch.stack([cam_d * torch.cos(el) * torch.cos(az), cam_d * torch.cos(el) * torch.sin(az),
+                       cam_d * torch.sin(el)], dim=-1)
+    center = torch.zeros_like(pos)
+    up = torch.tensor([0, 0, 1], dtype=dtype)[None].repeat(n_view, 1)
+    lookat = F.normalize(center - pos, dim=-1)
+    right = F.normalize(torch.linalg.cross(lookat, up), dim=-1)
+    up = F.normalize(torch.linalg.cross(right, lookat), dim=-1)
+    c2w3x4 = torch.cat([torch.stack([right, up, -lookat], dim=-1), pos[:, :, None]], dim=-1)
+    c2w = torch.cat([c2w3x4, torch.zeros_like(c2w3x4[:, :1])], dim=1)
+    c2w[:, 3, 3] = 1.0
+    focal = 0.5 * height / torch.tan(0.5 * fovy)
+    i, j = torch.meshgrid(torch.arange(width, dtype=dtype) + 0.5, torch.arange(height, dtype=dtype) + 0.5,
+                          indexing="xy")
+    dirs = torch.stack([(i - width / 2), -(j - height / 2), -torch.ones_like(i)], -1)
+    dirs = dirs[None].repeat(n_view, 1, 1, 1)
+    dirs[..., :2] = dirs[..., :2] / focal[:, None, None, None]
+    rays_d = (dirs[:, :, :, None, :] * c2w[:, None, None, :3, :3]).sum(-1)
+    rays_o = c2w[:, None, None, :3, 3].expand(rays_d.shape).contiguous()
+    rays_d = F.normalize(rays_d, dim=-1)
+    return rays_o, rays_d, c2w, cam_d
+
+
+def init_mlp_weights(dims: Sequence[int], gen: torch.Generator, dtype=torch.float32) -> List[Tensor]:
+    """nn.Linear default init (kaiming_uniform(a=sqrt(5)) => U(-1/sqrt(fan_in), 1/sqrt(fan_in))), bias-free."""
+    ws = []
+    for din, dout in zip(dims[:-1], dims[1:]):
+        bound = 1.0 / math.sqrt(din)
+        ws.append(((torch.rand(dout, din, generator=gen, dtype=torch.float64) * 2 - 1) * bound).to(dtype))
+    return ws
+
+
+def synthetic_loss(out: Dict[str, Tensor], proj: Dict[str, Tensor], lambda_sparsity: float = 1.0,
+                   lambda_eikonal: float = 1.0) -> Tensor:
+    """Fixed scalar loss of SURVEY.md G6: seeded random projections of the image-space outputs
+    + sparsity (multiprompt_dual_renderer_multistep_generator.py:635) + eikonal (:696-699)."""
+    loss = 0.0
+    for k, p in proj.items():
+        loss = loss + (out[k] * p).sum()
+    loss = loss + lambda_sparsity * (out["opacity"] ** 2 + 0.01).sqrt().mean()
+    loss = loss + lambda_eikonal * ((torch.linalg.norm(out["sdf_grad"], ord=2, dim=-1) - 1.0) ** 2).mean()
+    return loss
