@@ -1,0 +1,145 @@
+/*
+ * tt_abi.h -- C ABI of libtt_hip.so: the MI355X (gfx950) triplane volume-render hot path.
+ *
+ * This is the drop-in boundary of triplaneturbo_amd.  Every entry point is plain C:
+ * raw DEVICE pointers (fp32 unless noted), explicit sizes, a config struct, a hipStream_t
+ * passed as void*.  The caller (PyTorch-ROCm host code, or any FFI) allocates every output
+ * and workspace; nothing is allocated inside; no global state; re-entrant; safe from one
+ * host thread per device.  Return 0 on success, a negative tt_status on error (no C++
+ * exceptions cross the boundary).  tt_strerror() maps codes to text.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *
+ *   tt_planes_pack          few_step_triplane_dual_stable_diffusion.py:212-239 (rotate_planes "v1" copy)
+ *                           + geometry/utils.py:131 (view as N*n_planes,C,H,W); produces the channels-last,
+ *                           rotation-folded plane image the kernels gather from.
+ *   tt_planes_unpack_grad   the autograd transpose of the above (d loss / d space_cache, NCHW).
+ *   tt_query_points         StableDiffusionTriplaneDualAttention.forward   few_step...:273-351
+ *                           (= sample_from_planes geometry/utils.py:127-145 -> aten grid_sampler_2d,
+ *                            VanillaMLP networks.py:67-104, get_shifted_sdf :131-154, analytic normal :329-335
+ *                            -> aten grid_sampler_2d_backward via cuda_gridsample.py:55-58)
+ *                           and forward_sdf :353-373 (flags without TT_Q_TEX / TT_Q_NORMAL).
+ *   tt_render_fwd           GenerativeSpaceSDFVolumeRenderer._forward
+ *                           generative_space_sdf_volume_renderer.py:326-431,467-472 (positions, geometry,
+ *                           NoMaterial no_material.py:41-54, get_alpha neus_volume_renderer.py:93-117,
+ *                           nerfacc.render_weight_from_alpha, nerfacc.accumulate_along_rays x5).
+ *   tt_render_bwd_geo /     the autograd backward of the same, incl. the second-order terms the reference
+ *   tt_render_bwd_tex       obtains from gridsample_cuda.cu:27-210 (grad2_2d, cuda_gridsample.py:68-79),
+ *                           aten grid_sampler_2d_backward and the transposed cuBLAS GEMMs.
+ *   tt_grid_sample_2d_grad2 gridsample_cuda.cpp:26-37 `grad2_2d` itself (operator-level drop-in).
+ */
+#ifndef TT_ABI_H
+#define TT_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TT_ABI_VERSION 1
+#define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
+#define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
+
+typedef enum {
+    TT_OK = 0,
+    TT_ERR_BAD_ARG = -1,     /* null pointer / non-positive size / unsupported shape */
+    TT_ERR_UNSUPPORTED = -2, /* e.g. non-square planes */
+    TT_ERR_LAUNCH = -3,      /* hipLaunch / hipGetLastError failure */
+    TT_ERR_DEVICE = -4       /* not a gfx950 device / attribute query failed */
+} tt_status;
+
+/* MLP weights exactly as torch stores nn.Linear(bias=False).weight: row-major (out, in).
+ * sdf net  : w1 (64,32)  w2 (64,64)  w3 (1,64)     few_step...:101-105
+ * feat net : v1 (64,96)  v2 (64,64)  v3 (3,64)     few_step...:106-112  (tex_interpolate v2 => 96 inputs) */
+typedef struct {
+    const float* w1;
+    const float* w2;
+    const float* w3;
+    const float* v1;
+    const float* v2;
+    const float* v3;
+} tt_mlp_weights;
+
+typedef struct {
+    float* w1;
+    float* w2;
+    float* w3;
+    float* v1;
+    float* v2;
+    float* v3;
+} tt_mlp_grads; /* accumulated into (+=) with fp32 atomics; caller zero-initialises */
+
+typedef struct {
+    int32_t n_prompts;         /* P: planes are (P,6,H,W,32) packed */
+    int32_t views_per_prompt;  /* view b samples prompt b / views_per_prompt  (renderer :120-143) */
+    int32_t plane_h, plane_w;  /* must be equal (rotation v1 transposes) */
+    int32_t rays_per_view;     /* Hh*Ww; ray r belongs to view r / rays_per_view */
+    int32_t n_samples;         /* S samples per ray (dense layout, renderer :317-324) */
+    int64_t n_rays;            /* total rays = views * rays_per_view */
+    float radius;              /* geometry.radius: bbox = [-radius, radius]^3 */
+    float sdf_bias_radius;     /* sdf_bias "sphere", sdf_bias_params (yaml :78-79) */
+    float inv_std;             /* LearnedVariance.inv_std, clamped to [1e-6,1e6] (renderer :29-35) */
+    float cos_anneal_ratio;    /* neus_volume_renderer.py:101-104 */
+    float rgb_grad_shrink;     /* renderer :397-400 (backward only) */
+    int32_t flags;             /* TT_R_* */
+} tt_render_cfg;
+
+#define TT_R_PER_SAMPLE 1 /* also write per-sample sdf / sdf_grad / features (training extras, renderer :532-545) */
+
+/* tt_query_points flags */
+#define TT_Q_NORMAL 1 /* output sdf_grad (analytic normal path) */
+#define TT_Q_TEX 2    /* output features (texture planes + feature net) */
+
+const char* tt_strerror(int status);
+int tt_abi_version(void);
+
+/* space_cache (P,6,32,H,W) NCHW  ->  packed (P,6,H,W,32), planes re-oriented per rotate_planes "v1". */
+int tt_planes_pack(const float* space_cache, float* packed, int32_t n_prompts, int32_t plane_h, int32_t plane_w,
+                   void* stream);
+/* grad wrt packed (P,6,H,W,32) -> grad wrt space_cache (P,6,32,H,W); overwrites dst. */
+int tt_planes_unpack_grad(const float* grad_packed, float* grad_space_cache, int32_t n_prompts, int32_t plane_h,
+                          int32_t plane_w, void* stream);
+
+/* Per-point decode.  points (n_batch, n_points, 3) world units; batch b reads prompt b / views_per_prompt.
+ * out_sdf (n_batch*n_points), out_sdf_grad (n_batch*n_points,3) [if TT_Q_NORMAL], out_features (.,3) [if TT_Q_TEX].
+ * Null outputs are skipped. */
+int tt_query_points(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
+                    int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
+                    float radius, float sdf_bias_radius, int32_t flags, float* out_sdf, float* out_sdf_grad,
+                    float* out_features, void* stream);
+
+/* Forward render for explicit sample intervals.
+ * rays_o, rays_d (n_rays,3); t_starts, t_ends (n_rays,S).
+ * Per-ray outputs: opacity (n_rays), depth (n_rays), rgb_fg (n_rays,3), z_variance (n_rays),
+ *                  normal_acc (n_rays,3) = sum_i w_i n_i (NOT normalised).
+ * Per-sample outputs (n_rays*S): weights, trans (always written; trans is saved for backward);
+ *   sdf, sdf_grad (.,3), features (.,3) written when TT_R_PER_SAMPLE (may be null otherwise). */
+int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
+                  const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, float* opacity, float* depth,
+                  float* rgb_fg, float* z_variance, float* normal_acc, float* weights, float* trans, float* sdf,
+                  float* sdf_grad, float* features, void* stream);
+
+/* Backward, geometry half: d/d(geometry planes 0..2) and d/d(sdf net).
+ * Per-ray upstream grads (any may be null = 0): g_opacity, g_depth, g_rgb_fg(3), g_z_variance, g_normal_acc(3).
+ * Per-sample upstream grads (null = 0): g_weights, g_sdf, g_sdf_grad(3).
+ * Saved forward state: opacity, depth (per ray), trans, features (per sample).
+ * grad_packed (P,6,H,W,32) and mlp grads are accumulated into (caller zero-fills). */
+int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
+                      const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, const float* opacity,
+                      const float* depth, const float* trans, const float* features, const float* g_opacity,
+                      const float* g_depth, const float* g_rgb_fg, const float* g_z_variance,
+                      const float* g_normal_acc, const float* g_weights, const float* g_sdf, const float* g_sdf_grad,
+                      float* grad_packed, const tt_mlp_grads* grads, void* stream);
+
+/* Backward, texture half: d/d(texture planes 3..5) and d/d(feature net).
+ * Needs saved weights (per sample) and features; g_rgb_fg (per ray), g_features (per sample; null = 0). */
+int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
+                      const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, const float* weights,
+                      const float* features, const float* g_rgb_fg, const float* g_features, float* grad_packed,
+                      const tt_mlp_grads* grads, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TT_ABI_H */

@@ -318,7 +318,9 @@ def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Seq
     out["disparity"] = torch.clamp((far - disparity_tmp) / (far - near), 0.0, 1.0)
 
     # :466-505 (normal_direction == "camera")
-    comp_normal = F.normalize(accumulate(geo["normal"]), dim=-1)
+    normal_acc = accumulate(geo["normal"])
+    out["normal_acc"] = normal_acc  # un-normalised sum_i w_i n_i (what tt_render_fwd returns)
+    comp_normal = F.normalize(normal_acc, dim=-1)
     out["comp_normal"] = comp_normal.view(B, Hh, Ww, 3)
     bg_normal = 0.5 * torch.ones_like(comp_normal)
     bg_normal[:, 2] = 1.0

@@ -1,0 +1,122 @@
+"""Build + load libtt_hip.so (the C-ABI HIP library, include/tt_abi.h) with ctypes.
+
+There is NO fallback: if the shared library is missing or a symbol is absent the import of
+any op fails loudly.  ``build()`` cross-compiles for gfx950 with hipcc (works without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import List, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(_ROOT, "include")
+LIB_PATH = os.path.join(_HERE, "libtt_hip.so")
+SOURCES = ["tt_forward.hip", "tt_backward.hip", "tt_grad2.hip", "tt_host.cpp"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared", "-fno-gpu-rdc"]
+
+# every symbol include/tt_abi.h declares (tests check the header and this list agree)
+SYMBOLS = [
+    "tt_strerror", "tt_abi_version", "tt_planes_pack", "tt_planes_unpack_grad", "tt_query_points",
+    "tt_render_fwd",
+]
+
+
+def _sources() -> List[str]:
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = _sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(INCLUDE, "tt_abi.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 ... -shared -> triplaneturbo_amd/libtt_hip.so (in-tree)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC]
+    for s in _sources():
+        cmd += ["-x", "hip", s]
+    cmd += ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+_P = ctypes.c_void_p
+_I32 = ctypes.c_int32
+_I64 = ctypes.c_int64
+_F = ctypes.c_float
+
+
+class MlpWeights(ctypes.Structure):
+    _fields_ = [(n, _P) for n in ("w1", "w2", "w3", "v1", "v2", "v3")]
+
+
+class RenderCfg(ctypes.Structure):
+    _fields_ = [
+        ("n_prompts", _I32), ("views_per_prompt", _I32), ("plane_h", _I32), ("plane_w", _I32),
+        ("rays_per_view", _I32), ("n_samples", _I32), ("n_rays", _I64), ("radius", _F),
+        ("sdf_bias_radius", _F), ("inv_std", _F), ("cos_anneal_ratio", _F), ("rgb_grad_shrink", _F),
+        ("flags", _I32),
+    ]
+
+
+TT_R_PER_SAMPLE = 1
+TT_Q_NORMAL = 1
+TT_Q_TEX = 2
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (hipcc --offload-arch=gfx950). triplaneturbo_amd has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise RuntimeError(f"{LIB_PATH} lacks symbols {missing}; rebuild it")
+    lib.tt_strerror.restype = ctypes.c_char_p
+    lib.tt_strerror.argtypes = [ctypes.c_int]
+    lib.tt_abi_version.restype = ctypes.c_int
+    lib.tt_planes_pack.argtypes = [_P, _P, _I32, _I32, _I32, _P]
+    lib.tt_planes_unpack_grad.argtypes = [_P, _P, _I32, _I32, _I32, _P]
+    lib.tt_query_points.argtypes = [_P, ctypes.POINTER(MlpWeights), _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F,
+                                    _I32, _P, _P, _P, _P]
+    lib.tt_render_fwd.argtypes = [_P, ctypes.POINTER(MlpWeights), _P, _P, _P, _P, ctypes.POINTER(RenderCfg)] + [_P] * 11
+    _cfgp, _wp = ctypes.POINTER(RenderCfg), ctypes.POINTER(MlpWeights)
+    optional = {
+        "tt_render_bwd_geo": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 12 + [_P, _wp, _P],
+        "tt_render_bwd_tex": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 4 + [_P, _wp, _P],
+        "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 5 + [_P] * 3 + [_P],
+    }
+    for name, argtypes in optional.items():
+        if name in SYMBOLS:
+            getattr(lib, name).argtypes = argtypes
+    for name in SYMBOLS[2:]:
+        getattr(lib, name).restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f"{what} failed: {load().tt_strerror(status).decode()} ({status})")

@@ -1,0 +1,295 @@
+// tt_device.h -- device-side building blocks shared by the forward and backward kernels.
+//
+// gfx950 / CDNA4 only.  Everything here is wave64 code built around one convention:
+//
+//   A wave owns a TILE of 32 samples.  Lane l = (j, hi) with j = l & 31 (sample within the tile) and
+//   hi = l >> 5 (which half of every feature/hidden vector the lane holds).  A length-32n vector v is
+//   held as 16n registers per lane with   reg r  <->  element  LIDX(r, hi) = (r&3) + 8*(r>>2) + 4*hi.
+//
+// That map is exactly the C/D register layout of v_mfma_f32_32x32x2_f32 (col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), so when the per-point MLP is written "transposed"
+// (D[hidden x samples] = W[hidden x k] * X[k x samples], weights as the A operand, samples as the 32
+// columns of B) the output registers of one layer ARE the B operand registers of the next layer:
+// k-step r of the next layer pairs element LIDX(r,0) (lanes 0-31) with LIDX(r,1) (lanes 32-63), and the
+// A operand simply reads the matching weight column.  No shuffles, no LDS round trip between layers,
+// exact fp32 (the f32 MFMA is a k-ordered fmaf chain).  The plane gather uses the same map: lane (j,hi)
+// loads the 16-byte chunks {hi, hi+2, hi+4, hi+6} of each 128-byte channels-last texel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TT_C 32
+#define TT_HID 64
+#define TT_TILE 32
+
+#define LIDX(r, hi) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hi))
+
+// ---- LDS image of the MLP weights: row-major, row stride = cols + 4 floats -----------------------
+// (+4 keeps 16-byte alignment and makes the per-lane-row ds_read_b128 of mv_fwd conflict-free:
+//  36*i, 68*i, 100*i mod 64 hit 16 distinct 4-bank slots for the 16 lanes of a b128 lane group.)
+#define W1S 36
+#define W2S 68
+#define V1S 100
+#define V2S 68
+#define OFF_W1 0
+#define OFF_W2 (OFF_W1 + 64 * W1S)
+#define OFF_W3 (OFF_W2 + 64 * W2S)
+#define OFF_V1 (OFF_W3 + 64)
+#define OFF_V2 (OFF_V1 + 64 * V1S)
+#define OFF_V3 (OFF_V2 + 64 * V2S)
+#define LDS_W_FLOATS (OFF_V3 + 3 * 64)
+#define LDS_GEO_FLOATS (OFF_W3 + 64) /* W1, W2, w3 only */
+
+struct MlpPtrs {
+    const float* w1;
+    const float* w2;
+    const float* w3;
+    const float* v1;
+    const float* v2;
+    const float* v3;
+};
+
+__device__ __forceinline__ void lds_load_matrix(float* dst, const float* __restrict__ src, int rows, int cols,
+                                                int stride) {
+    for (int e = threadIdx.x; e < rows * cols; e += blockDim.x) {
+        int r = e / cols, c = e - r * cols;
+        dst[r * stride + c] = src[e];
+    }
+}
+
+__device__ __forceinline__ void lds_load_geo_weights(float* L, const MlpPtrs& w) {
+    lds_load_matrix(L + OFF_W1, w.w1, 64, 32, W1S);
+    lds_load_matrix(L + OFF_W2, w.w2, 64, 64, W2S);
+    lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
+}
+__device__ __forceinline__ void lds_load_tex_weights(float* L, const MlpPtrs& w) {
+    lds_load_matrix(L + OFF_V1, w.v1, 64, 96, V1S);
+    lds_load_matrix(L + OFF_V2, w.v2, 64, 64, V2S);
+    lds_load_matrix(L + OFF_V3, w.v3, 3, 64, 64);
+}
+
+// ---- MFMA mat-vec products on a 32-sample tile -----------------------------------------------------
+// y[NOUT] = W[NOUT][NIN] * x[NIN]   (W in LDS, row stride NIN+4).  x, y in the LIDX register layout.
+template <int NOUT, int NIN>
+__device__ __forceinline__ void mv_fwd(const float* Wl, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i,
+                                       int hi) {
+#pragma unroll
+    for (int m = 0; m < NOUT / 32; ++m) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* row = Wl + (32 * m + i) * (NIN + 4) + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < NIN / 8; ++g) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(row + 8 * g);  // columns LIDX(4g..4g+3, hi)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x[4 * g + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], x[4 * g + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], x[4 * g + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], x[4 * g + 3], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[k];
+    }
+}
+
+// y[NOUT] = W[NIN][NOUT]^T * x[NIN]   (W in LDS as stored, row stride NOUT+4).
+template <int NOUT, int NIN>
+__device__ __forceinline__ void mv_bwd(const float* Wl, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i,
+                                       int hi) {
+    const float* base = Wl + 4 * hi * (NOUT + 4) + i;
+#pragma unroll
+    for (int m = 0; m < NOUT / 32; ++m) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < NIN / 2; ++r) {
+            float a = base[LIDX(r, 0) * (NOUT + 4) + 32 * m];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[r], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[k];
+    }
+}
+
+// dot of a register vector with an LDS vector w[N] (same LIDX layout), summed over both halves.
+template <int N>
+__device__ __forceinline__ float dot_lds(const float* wl, const float (&x)[N / 2], int hi) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < N / 8; ++g) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(wl + 8 * g + 4 * hi);
+        s = fmaf(a[0], x[4 * g + 0], s);
+        s = fmaf(a[1], x[4 * g + 1], s);
+        s = fmaf(a[2], x[4 * g + 2], s);
+        s = fmaf(a[3], x[4 * g + 3], s);
+    }
+    return s + __shfl_xor(s, 32);
+}
+
+// ---- bilinear corner set-up (ATen GridSampler.cuh:23-31; zeros padding, align_corners=False) -------
+struct Corners {
+    int off[4];   // texel index y*W+x (clamped to 0 when out of bounds)
+    float w[4];   // bilinear weights nw, ne, sw, se (0 when out of bounds)
+    float du[4];  // d w / d ix   (0 when out of bounds)
+    float dv[4];  // d w / d iy
+    bool any;     // any corner in bounds
+};
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ void corners_setup(float gx, float gy, int H, int W, bool valid, Corners& c) {
+    // same op order as the reference: ((coord + 1) * size - 1) / 2
+    float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+    float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    float fx = floorf(ix), fy = floorf(iy);
+    float wx1 = ix - fx, wx0 = (fx + 1.f) - ix;
+    float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+    int x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f);
+    int y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+    bool bx0 = valid && x0 >= 0 && x0 < W, bx1 = valid && x0 + 1 >= 0 && x0 + 1 < W;
+    bool by0 = y0 >= 0 && y0 < H, by1 = y0 + 1 >= 0 && y0 + 1 < H;
+    bool in0 = bx0 && by0, in1 = bx1 && by0, in2 = bx0 && by1, in3 = bx1 && by1;
+    c.w[0] = in0 ? wx0 * wy0 : 0.f;
+    c.w[1] = in1 ? wx1 * wy0 : 0.f;
+    c.w[2] = in2 ? wx0 * wy1 : 0.f;
+    c.w[3] = in3 ? wx1 * wy1 : 0.f;
+    c.du[0] = in0 ? -wy0 : 0.f;
+    c.du[1] = in1 ? wy0 : 0.f;
+    c.du[2] = in2 ? -wy1 : 0.f;
+    c.du[3] = in3 ? wy1 : 0.f;
+    c.dv[0] = in0 ? -wx0 : 0.f;
+    c.dv[1] = in1 ? -wx1 : 0.f;
+    c.dv[2] = in2 ? wx0 : 0.f;
+    c.dv[3] = in3 ? wx1 : 0.f;
+    c.off[0] = in0 ? y0 * W + x0 : 0;
+    c.off[1] = in1 ? y0 * W + x0 + 1 : 0;
+    c.off[2] = in2 ? (y0 + 1) * W + x0 : 0;
+    c.off[3] = in3 ? (y0 + 1) * W + x0 + 1 : 0;
+    c.any = in0 || in1 || in2 || in3;
+}
+
+// world position -> plane-sampling coordinates, mirroring the reference's fp32 op order:
+//   scale_tensor(x, (-radius, radius), (-1, 1))  (threestudio/utils/ops.py:27-38)  then * (2/box_warp) = * 1
+__device__ __forceinline__ float scale_coord(float x, float radius) {
+    float t = (x - (-radius)) / (radius - (-radius));
+    return t * 2.f + (-1.f);
+}
+
+__device__ __forceinline__ void sample_position(float ox, float oy, float oz, float dx, float dy, float dz, float ts,
+                                                float te, float& tm, float& px, float& py, float& pz) {
+    tm = (ts + te) / 2.f;  // renderer :337
+    px = ox + dx * tm;     // renderer :338
+    py = oy + dy * tm;
+    pz = oz + dz * tm;
+}
+
+__device__ __forceinline__ float sphere_bias(float px, float py, float pz, float bias_radius, float& nrm) {
+    nrm = sqrtf((px * px + py * py) + pz * pz);  // few_step...:146-149
+    return nrm - bias_radius;
+}
+#pragma clang fp contract(fast)
+
+// plane p uses (u,v): p0 (x,y), p1 (x,z), p2 (z,y)  (geometry/utils.py:46-63,111-125)
+#define PLANE_U(p, X, Y, Z) ((p) == 2 ? (Z) : (X))
+#define PLANE_V(p, X, Y, Z) ((p) == 1 ? (Z) : (Y))
+
+// ---- gathers ----------------------------------------------------------------------------------------
+// geometry planes (v1 = sum over planes): f[16] and, if NEED_J, J = d f / d(world xyz) (3 x 16)
+template <bool NEED_J>
+__device__ __forceinline__ bool gather_geo(const float* __restrict__ planes, int H, int W, float X, float Y, float Z,
+                                           bool valid, float jscale_u, float jscale_v, int hi, float (&f)[16],
+                                           float (&jx)[16], float (&jy)[16], float (&jz)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        f[r] = 0.f;
+        jx[r] = 0.f;
+        jy[r] = 0.f;
+        jz[r] = 0.f;
+    }
+    bool any = false;
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        Corners c;
+        corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, c);
+        if (!__any(c.any)) continue;  // exact: every contribution of this plane is 0 for the whole tile
+        any = any || c.any;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4* t = reinterpret_cast<const f32x4*>(planes + (p * HW + (size_t)c.off[k]) * TT_C) + hi;
+            f32x4 v[4] = {t[0], t[2], t[4], t[6]};
+            const float wk = c.w[k], a = c.du[k] * jscale_u, b = c.dv[k] * jscale_v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tv = v[q][e];
+                    f[4 * q + e] = fmaf(wk, tv, f[4 * q + e]);
+                    if (NEED_J) {
+                        if (p == 0) {
+                            jx[4 * q + e] = fmaf(a, tv, jx[4 * q + e]);
+                            jy[4 * q + e] = fmaf(b, tv, jy[4 * q + e]);
+                        } else if (p == 1) {
+                            jx[4 * q + e] = fmaf(a, tv, jx[4 * q + e]);
+                            jz[4 * q + e] = fmaf(b, tv, jz[4 * q + e]);
+                        } else {
+                            jz[4 * q + e] = fmaf(a, tv, jz[4 * q + e]);
+                            jy[4 * q + e] = fmaf(b, tv, jy[4 * q + e]);
+                        }
+                    }
+                }
+        }
+    }
+    return any;
+}
+
+// texture planes (v2 = concat over planes): e[48], e[16p + r] <-> channel LIDX(r,hi) of plane p
+__device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int H, int W, float X, float Y, float Z,
+                                           bool valid, int hi, float (&e)[48]) {
+#pragma unroll
+    for (int r = 0; r < 48; ++r) e[r] = 0.f;
+    bool any = false;
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        Corners c;
+        corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, c);
+        if (!__any(c.any)) continue;
+        any = any || c.any;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4* t = reinterpret_cast<const f32x4*>(planes + ((3 + p) * HW + (size_t)c.off[k]) * TT_C) + hi;
+            f32x4 v[4] = {t[0], t[2], t[4], t[6]};
+            const float wk = c.w[k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) e[16 * p + 4 * q + ee] = fmaf(wk, v[q][ee], e[16 * p + 4 * q + ee]);
+        }
+    }
+    return any;
+}
+
+// ---- wave scans over the 32 samples of a tile (both halves run the same scan redundantly) -----------
+__device__ __forceinline__ float half_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    return v;
+}
+
+// exclusive prefix product over lanes j = 0..31 of each half; total = product over the whole tile
+__device__ __forceinline__ float excl_prod32(float v, int j, float& total) {
+    float inc = v;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        float o = __shfl_up(inc, d, 32);
+        if (j >= d) inc *= o;
+    }
+    total = __shfl(inc, 31, 32);
+    float ex = __shfl_up(inc, 1, 32);
+    return j == 0 ? 1.f : ex;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }

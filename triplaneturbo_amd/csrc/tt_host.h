@@ -1,0 +1,9 @@
+// tt_host.h -- host-side helpers shared by the translation units of libtt_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/tt_abi.h"
+
+int tt_check_launch();
+int tt_num_cus();
+int tt_validate_cfg(const tt_render_cfg* cfg);

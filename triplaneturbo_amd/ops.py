@@ -1,0 +1,142 @@
+"""Torch-facing wrappers over the C ABI (include/tt_abi.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; all arithmetic of the hot path
+happens in libtt_hip.so.  Tensors must be CUDA(=HIP) fp32; there is no CPU fallback (a CPU tensor raises).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+
+
+def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: Tensor, name: str, shape: Optional[Sequence[int]] = None) -> Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (triplaneturbo_amd has no CPU path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t.contiguous()
+
+
+def _weights_struct(sdf_w: Sequence[Tensor], feat_w: Optional[Sequence[Tensor]]):
+    sw = [_chk(sdf_w[0], "sdf w1", (64, 32)), _chk(sdf_w[1], "sdf w2", (64, 64)), _chk(sdf_w[2], "sdf w3", (1, 64))]
+    fw: List[Optional[Tensor]] = [None, None, None]
+    if feat_w is not None:
+        fw = [_chk(feat_w[0], "feat v1", (64, 96)), _chk(feat_w[1], "feat v2", (64, 64)),
+              _chk(feat_w[2], "feat v3", (3, 64))]
+    st = _lib.MlpWeights(*[_ptr(t) for t in sw + fw])
+    return st, sw + fw  # keep tensors alive
+
+
+@dataclass
+class RenderConfig:
+    """Scalar knobs of GenerativeSpaceSDFVolumeRenderer that reach the kernels (reference renderer :40-71)."""
+    radius: float = 1.0
+    sdf_bias_radius: float = 0.5
+    inv_std: float = 100.0
+    cos_anneal_ratio: float = 1.0
+    rgb_grad_shrink: float = 1.0
+
+
+def planes_pack(space_cache: Tensor) -> Tensor:
+    """(P,6,32,H,W) generator output -> (P,6,H,W,32) channels-last, rotate_planes 'v1' folded in."""
+    space_cache = _chk(space_cache, "space_cache")
+    if space_cache.ndim != 5 or space_cache.shape[1] != 6 or space_cache.shape[2] != 32:
+        raise ValueError(f"space_cache must be (P,6,32,H,W), got {tuple(space_cache.shape)}")
+    P, _, _, H, W = space_cache.shape
+    out = torch.empty((P, 6, H, W, 32), device=space_cache.device, dtype=torch.float32)
+    _lib.check(_lib.load().tt_planes_pack(_ptr(space_cache), _ptr(out), P, H, W, _stream()), "tt_planes_pack")
+    return out
+
+
+def planes_unpack_grad(grad_packed: Tensor) -> Tensor:
+    grad_packed = _chk(grad_packed, "grad_packed")
+    P, _, H, W, _ = grad_packed.shape
+    out = torch.empty((P, 6, 32, H, W), device=grad_packed.device, dtype=torch.float32)
+    _lib.check(_lib.load().tt_planes_unpack_grad(_ptr(grad_packed), _ptr(out), P, H, W, _stream()),
+               "tt_planes_unpack_grad")
+    return out
+
+
+def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Sequence[Tensor]], points: Tensor,
+                 views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5,
+                 need_normal: bool = True, need_features: bool = True):
+    """Per-point decode (no grad). points (B,N,3) -> sdf (B*N,1), sdf_grad (B*N,3)|None, features (B*N,3)|None."""
+    packed = _chk(packed, "packed")
+    points = _chk(points, "points")
+    B, N, _ = points.shape
+    P, _, H, W, _ = packed.shape
+    wst, keep = _weights_struct(sdf_w, feat_w if need_features else None)
+    dev = points.device
+    sdf = torch.empty((B * N, 1), device=dev, dtype=torch.float32)
+    grad = torch.empty((B * N, 3), device=dev, dtype=torch.float32) if need_normal else None
+    feat = torch.empty((B * N, 3), device=dev, dtype=torch.float32) if need_features else None
+    flags = (_lib.TT_Q_NORMAL if need_normal else 0) | (_lib.TT_Q_TEX if need_features else 0)
+    st = _lib.load().tt_query_points(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, views_per_prompt, H, W,
+                                     radius, sdf_bias_radius, flags, _ptr(sdf), _ptr(grad), _ptr(feat), _stream())
+    _lib.check(st, "tt_query_points")
+    return sdf, grad, feat
+
+
+def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, rc: RenderConfig,
+              per_sample: bool) -> "_lib.RenderCfg":
+    P, _, H, W, _ = packed.shape
+    n_views = n_rays // rays_per_view
+    if n_views * rays_per_view != n_rays or n_views % P != 0:
+        raise ValueError(f"n_rays={n_rays} is not views*rays_per_view with views a multiple of P={P}")
+    inv_std = min(max(float(rc.inv_std), 1.0e-6), 1.0e6)  # LearnedVariance.forward clamp, renderer :34-35
+    return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
+                          inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
+                          _lib.TT_R_PER_SAMPLE if per_sample else 0)
+
+
+def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
+                       rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, rays_per_view: int, rc: RenderConfig,
+                       per_sample: bool = True):
+    """One tt_render_fwd launch.  rays_* (n_rays,3); t_* (n_rays,S).  Returns a dict of raw kernel outputs."""
+    packed = _chk(packed, "packed")
+    rays_o, rays_d = _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d")
+    t_starts, t_ends = _chk(t_starts, "t_starts"), _chk(t_ends, "t_ends")
+    n_rays, S = t_starts.shape
+    if rays_o.shape != (n_rays, 3) or rays_d.shape != (n_rays, 3) or t_ends.shape != (n_rays, S):
+        raise ValueError("ray / interval shapes disagree")
+    cfg = _make_cfg(packed, n_rays, rays_per_view, S, rc, per_sample)
+    wst, keep = _weights_struct(sdf_w, feat_w)
+    dev = packed.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = {
+        "opacity": torch.empty((n_rays, 1), **f32), "depth": torch.empty((n_rays, 1), **f32),
+        "rgb_fg": torch.empty((n_rays, 3), **f32), "z_variance": torch.empty((n_rays, 1), **f32),
+        "normal_acc": torch.empty((n_rays, 3), **f32),
+        "weights": torch.empty((n_rays * S, 1), **f32), "trans": torch.empty((n_rays * S, 1), **f32),
+    }
+    if per_sample:
+        out.update(sdf=torch.empty((n_rays * S, 1), **f32), sdf_grad=torch.empty((n_rays * S, 3), **f32),
+                   features=torch.empty((n_rays * S, 3), **f32))
+    st = _lib.load().tt_render_fwd(
+        _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends), ctypes.byref(cfg),
+        _ptr(out["opacity"]), _ptr(out["depth"]), _ptr(out["rgb_fg"]), _ptr(out["z_variance"]),
+        _ptr(out["normal_acc"]), _ptr(out["weights"]), _ptr(out["trans"]), _ptr(out.get("sdf")),
+        _ptr(out.get("sdf_grad")), _ptr(out.get("features")), _stream())
+    _lib.check(st, "tt_render_fwd")
+    return out
