@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomic
 # every symbol include/tt_abi.h declares (tests check the header and this list agree)
 SYMBOLS = [
     "tt_strerror", "tt_abi_version", "tt_planes_pack", "tt_planes_unpack_grad", "tt_query_points",
-    "tt_render_fwd",
+    "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex",
 ]
 
 

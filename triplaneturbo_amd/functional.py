@@ -1,0 +1,95 @@
+"""Renderer-level composite on top of the fused op: everything GenerativeSpaceSDFVolumeRenderer._forward does
+with the per-ray accumulators (reference generative_space_sdf_volume_renderer.py:433-546).  These are a handful
+of (n_rays, .)-sized torch ops; the per-sample hot path lives in the HIP kernels."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
+                  rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, bg_color: Tensor, camera_distances: Tensor,
+                  c2w: Tensor, rc: ops.RenderConfig, training: bool = True,
+                  normal_direction: str = "camera", comp_rgb_bg: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """rays_o/rays_d (B,H,W,3); t_starts/t_ends (B*H*W, S); bg_color (3,), (B*H*W,3) or (B,H,W,3)."""
+    B, Hh, Ww, _ = rays_o.shape
+    n_rays = B * Hh * Ww
+    S = t_starts.shape[1]
+    ro = rays_o.reshape(n_rays, 3)
+    rd = rays_d.reshape(n_rays, 3)
+    r = ops.render_samples(space_cache, sdf_w, feat_w, ro, rd, t_starts, t_ends, Hh * Ww, rc)
+    opacity, depth, comp_rgb_fg, z_variance = r["opacity"], r["depth"], r["rgb_fg"], r["z_variance"]
+
+    if bg_color.ndim == 1:
+        bg = bg_color[None, :].expand(n_rays, -1)
+    else:
+        bg = bg_color.reshape(n_rays, -1)  # renderer :436-437
+    comp_rgb = comp_rgb_fg + bg * (1.0 - opacity)  # :439
+    if comp_rgb_bg is None:
+        comp_rgb_bg = bg
+    out = {
+        "comp_rgb": comp_rgb.view(B, Hh, Ww, -1),
+        "comp_rgb_fg": comp_rgb_fg.view(B, Hh, Ww, -1),
+        "comp_rgb_bg": comp_rgb_bg.reshape(B, Hh, Ww, -1),
+        "opacity": opacity.view(B, Hh, Ww, 1),
+        "depth": depth.view(B, Hh, Ww, 1),
+        "z_variance": z_variance.view(B, Hh, Ww, 1),
+    }
+    # :452-462
+    cd = camera_distances.reshape(-1, 1, 1, 1)
+    far = cd + math.sqrt(3.0)
+    near = cd - math.sqrt(3.0)
+    disparity_tmp = out["depth"] * out["opacity"] + (1.0 - out["opacity"]) * far
+    out["disparity"] = torch.clamp((far - disparity_tmp) / (far - near), 0.0, 1.0).view(B, Hh, Ww, 1)
+
+    # :466-530
+    comp_normal = F.normalize(r["normal_acc"], dim=-1)
+    out["comp_normal"] = comp_normal.view(B, Hh, Ww, 3)
+    if normal_direction == "camera":
+        bg_normal = 0.5 * torch.ones_like(comp_normal)
+        bg_normal[:, 2] = 1.0
+        bg_normal_white = torch.ones_like(comp_normal)
+        w2c = torch.inverse(c2w)
+        rot = w2c[:, :3, :3]
+        comp_normal_cam = comp_normal.view(B, -1, 3) @ rot.permute(0, 2, 1)
+        flip_x = torch.eye(3, device=comp_normal.device, dtype=comp_normal.dtype)
+        flip_x[0, 0] = -1
+        comp_normal_cam = (comp_normal_cam @ flip_x[None]).view(-1, 3)
+        out["comp_normal_cam_vis"] = ((comp_normal_cam + 1.0) / 2.0 * opacity + (1 - opacity) * bg_normal).view(
+            B, Hh, Ww, 3)
+        out["comp_normal_cam_vis_white"] = (
+            (comp_normal_cam + 1.0) / 2.0 * opacity + (1 - opacity) * bg_normal_white).view(B, Hh, Ww, 3)
+    elif normal_direction == "front":
+        n_prompts = space_cache.shape[0]
+        nv = B // n_prompts
+        bg_normal_white = torch.ones_like(comp_normal)
+        c2w_front = c2w[0::nv].repeat_interleave(nv, dim=0)
+        rot = torch.inverse(c2w_front)[:, :3, :3]
+        comp_normal_front = (comp_normal.view(B, -1, 3) @ rot.permute(0, 2, 1)).view(-1, 3)
+        out["comp_normal_cam_vis_white"] = (
+            (comp_normal_front + 1.0) / 2.0 * opacity + (1 - opacity) * bg_normal_white).view(B, Hh, Ww, 3)
+    elif normal_direction != "world":
+        raise ValueError(normal_direction)
+
+    if training:  # :532-545
+        t_positions = ((t_starts + t_ends) / 2.0).reshape(-1, 1)
+        t_intervals = (t_ends - t_starts).reshape(-1, 1)
+        ray_indices = torch.arange(n_rays, device=ro.device).unsqueeze(-1).expand(-1, S).reshape(-1)
+        t_dirs = rd[ray_indices]
+        positions = ro[ray_indices] + t_dirs * t_positions
+        sdf_grad = r["sdf_grad"]
+        normal = F.normalize(sdf_grad, dim=-1)
+        sdf = r["sdf"]
+        sdf_bias = (positions ** 2).sum(dim=-1, keepdim=True).sqrt() - rc.sdf_bias_radius
+        out.update(weights=r["weights"], t_points=t_positions, t_intervals=t_intervals, t_dirs=t_dirs,
+                   ray_indices=ray_indices, points=positions, sdf=sdf, sdf_orig=sdf - sdf_bias,
+                   features=r["features"], normal=normal, shading_normal=normal, sdf_grad=sdf_grad,
+                   inv_std=torch.as_tensor(rc.inv_std, device=ro.device))
+    return out

@@ -140,3 +140,71 @@ def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
         _ptr(out.get("sdf_grad")), _ptr(out.get("features")), _stream())
     _lib.check(st, "tt_render_fwd")
     return out
+
+
+def _grads_struct(tensors: Sequence[Tensor]):
+    return _lib.MlpWeights(*[_ptr(t) for t in tensors])  # same layout as tt_mlp_grads (6 pointers)
+
+
+class _TriplaneRenderFn(torch.autograd.Function):
+    """Differentiable fused render.  forward = tt_planes_pack + tt_render_fwd; backward = tt_render_bwd_geo +
+    tt_render_bwd_tex + tt_planes_unpack_grad.  Differentiable inputs: space_cache and the six MLP weights
+    (sample positions are constants: the reference's sampler runs under no_grad, estimators.py:22)."""
+
+    @staticmethod
+    def forward(ctx, space_cache, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, rays_per_view, rc):
+        packed = planes_pack(space_cache)
+        need_grad = any(ctx.needs_input_grad[:7])
+        raw = render_forward_raw(packed, (w1, w2, w3), (v1, v2, v3), rays_o, rays_d, t_starts, t_ends, rays_per_view,
+                                 rc, per_sample=True)
+        ctx.rays_per_view = rays_per_view
+        ctx.rc = rc
+        if need_grad:
+            ctx.save_for_backward(packed, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, raw["opacity"],
+                                  raw["depth"], raw["trans"], raw["weights"], raw["features"])
+        ctx.mark_non_differentiable(raw["trans"])
+        return (raw["opacity"], raw["depth"], raw["rgb_fg"], raw["z_variance"], raw["normal_acc"], raw["weights"],
+                raw["sdf"], raw["sdf_grad"], raw["features"], raw["trans"])
+
+    @staticmethod
+    def backward(ctx, g_op, g_depth, g_rgb, g_zvar, g_nacc, g_weights, g_sdf, g_sdf_grad, g_features, _g_trans):
+        (packed, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, opacity, depth, trans, weights,
+         features) = ctx.saved_tensors
+        n_rays, S = t_starts.shape
+        cfg = _make_cfg(packed, n_rays, ctx.rays_per_view, S, ctx.rc, True)
+        wst, keep = _weights_struct((w1, w2, w3), (v1, v2, v3))
+        grad_packed = torch.zeros_like(packed)
+        gw = [torch.zeros_like(t) for t in (w1, w2, w3, v1, v2, v3)]
+        gst = _grads_struct(gw)
+
+        def c(t):
+            return None if t is None else t.contiguous()
+
+        g_op, g_depth, g_rgb, g_zvar, g_nacc = c(g_op), c(g_depth), c(g_rgb), c(g_zvar), c(g_nacc)
+        g_weights, g_sdf, g_sdf_grad, g_features = c(g_weights), c(g_sdf), c(g_sdf_grad), c(g_features)
+        lib = _lib.load()
+        st = lib.tt_render_bwd_geo(
+            _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
+            ctypes.byref(cfg), _ptr(opacity), _ptr(depth), _ptr(trans), _ptr(features), _ptr(g_op), _ptr(g_depth),
+            _ptr(g_rgb), _ptr(g_zvar), _ptr(g_nacc), _ptr(g_weights), _ptr(g_sdf), _ptr(g_sdf_grad),
+            _ptr(grad_packed), ctypes.byref(gst), _stream())
+        _lib.check(st, "tt_render_bwd_geo")
+        st = lib.tt_render_bwd_tex(
+            _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
+            ctypes.byref(cfg), _ptr(weights), _ptr(features), _ptr(g_rgb), _ptr(g_features), _ptr(grad_packed),
+            ctypes.byref(gst), _stream())
+        _lib.check(st, "tt_render_bwd_tex")
+        g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
+        return (g_cache, *gw, None, None, None, None, None, None)
+
+
+def render_samples(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
+                   rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, rays_per_view: int, rc: RenderConfig):
+    """Differentiable fused render for explicit sample intervals.  Returns a dict of per-ray accumulators and
+    per-sample tensors (autograd-connected to space_cache and the MLP weights)."""
+    names = ("opacity", "depth", "rgb_fg", "z_variance", "normal_acc", "weights", "sdf", "sdf_grad", "features",
+             "trans")
+    outs = _TriplaneRenderFn.apply(space_cache, sdf_w[0], sdf_w[1], sdf_w[2], feat_w[0], feat_w[1], feat_w[2],
+                                   rays_o.contiguous(), rays_d.contiguous(), t_starts.contiguous(),
+                                   t_ends.contiguous(), rays_per_view, rc)
+    return dict(zip(names, outs))
