@@ -1,0 +1,38 @@
+"""Dev tool: per-kernel timings of one C2 step, optionally with profiling-only ablation flags.
+usage: python tools/profile_kernels.py [steps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from triplaneturbo_amd import functional, ops  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+dev = torch.device("cuda", 0)
+inp = bench.make_inputs(0, dev)
+rc = ops.RenderConfig()
+params = [inp["cache"]] + inp["sw"] + inp["fw"]
+
+
+def step():
+    for t in params:
+        t.grad = None
+    out = functional.volume_render(inp["cache"], inp["sw"], inp["fw"], inp["ro"], inp["rd"], inp["ts"], inp["te"],
+                                   inp["bg"], inp["cd"], inp["c2w"], rc, training=True)
+    bench.loss_fn(out, inp["proj"]).backward()
+
+
+for name, flags in (("full", "0"), ("no_scatter", "0x100"), ("no_wgrad", "0x200"), ("no_scatter_no_wgrad", "0x300")):
+    if len(sys.argv) > 2 and sys.argv[2] == "fullonly" and name != "full":
+        continue
+    os.environ["TT_DEBUG_FLAGS"] = flags
+    step()
+    t = ops.KernelTimer()
+    ops.set_kernel_timer(t)
+    torch.cuda.synchronize()
+    for _ in range(steps):
+        step()
+    ops.set_kernel_timer(None)
+    print(name, {k: round(v[0], 3) for k, v in t.summary().items()}, flush=True)

@@ -13,7 +13,11 @@
 // Everything per-sample is RECOMPUTED from the planes; the forward saves only trans / weights / features.
 #include "tt_device.h"
 #include "tt_host.h"
+#include <stdlib.h>
 
+#define TT_DBG_NO_SCATTER 0x100  // profiling-only ablations (set through TT_DEBUG_FLAGS; results are then wrong)
+#define TT_DBG_NO_WGRAD 0x200
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define XS 36  // row stride (floats) of the [index][sample] transposition scratch
 
 // ---- LDS transposition helpers (wave-private scratch; DS ops of one wave execute in order) ----------
@@ -285,9 +289,12 @@ __global__ __launch_bounds__(256, 1) void k_render_bwd_geo(BwdGeoParams p) {
                     u[r] = fmaf(sbar, f[r], qb[r]);
                 }
                 // dW1 += a1 (sbar f + qbar)^T
-                stage_rows<64>(Xs, a1, i, hi);
-                stage_rows<32>(Ys, u, i, hi);
-                wgrad<64, 32>(accW1, Xs, Ys, i, hi);
+                const bool do_wgrad = !(cfg.flags & TT_DBG_NO_WGRAD);
+                if (do_wgrad) {
+                    stage_rows<64>(Xs, a1, i, hi);
+                    stage_rows<32>(Ys, u, i, hi);
+                    wgrad<64, 32>(accW1, Xs, Ys, i, hi);
+                }
                 // a1bar = W1 qbar ; b1bar = m1 . a1bar ; v = sbar h1 + b1bar
                 float t1[32];
                 mv_fwd<64, 32>(L + OFF_W1, qb, t1, i, hi);
@@ -297,9 +304,11 @@ __global__ __launch_bounds__(256, 1) void k_render_bwd_geo(BwdGeoParams p) {
 #pragma unroll
                 for (int r = 0; r < 32; ++r) v[r] = fmaf(sbar, h1[r], t1[r]);
                 // dW2 += a2 v^T
-                stage_rows<64>(Xs, a2, i, hi);
-                stage_rows<64>(Ys, v, i, hi);
-                wgrad<64, 64>(accW2, Xs, Ys, i, hi);
+                if (do_wgrad) {
+                    stage_rows<64>(Xs, a2, i, hi);
+                    stage_rows<64>(Ys, v, i, hi);
+                    wgrad<64, 64>(accW2, Xs, Ys, i, hi);
+                }
                 // a2bar = W2 b1bar ; dw3 += sbar h2 + m2 . a2bar
                 float t2[32];
                 mv_fwd<64, 64>(L + OFF_W2, t1, t2, i, hi);
@@ -328,14 +337,26 @@ __global__ __launch_bounds__(256, 1) void k_render_bwd_geo(BwdGeoParams p) {
                     }
                 }
                 float* gp = p.grad_packed + pofs;
-#pragma nounroll
-                for (int it = 0; it < 192; ++it) {
-                    const int kk = 2 * it + hi;  // (sample, corner) pair handled by this half-wave
-                    const int s = kk / 12, cc = kk - s * 12;
-                    const float coef = Cs[s * 12 + cc];
-                    if (coef != 0.f) {
-                        const float val = Qs[s * 33 + i] * coef;
-                        atomicAdd(gp + (size_t)Os[s * 12 + cc] * TT_C + i, val);
+                if (!(cfg.flags & TT_DBG_NO_SCATTER)) {
+#pragma unroll 2
+                    for (int it = 0; it < 16; ++it) {
+                        const int s = 2 * it + hi;  // each half-wave scatters one sample per iteration
+                        const float qv = Qs[s * 33 + i];
+                        float cf[12];
+                        int of[12];
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            const f32x4 c4 = *reinterpret_cast<const f32x4*>(Cs + s * 12 + 4 * g);
+                            const i32x4 o4 = *reinterpret_cast<const i32x4*>(Os + s * 12 + 4 * g);
+#pragma unroll
+                            for (int e2 = 0; e2 < 4; ++e2) {
+                                cf[4 * g + e2] = c4[e2];
+                                of[4 * g + e2] = o4[e2];
+                            }
+                        }
+#pragma unroll
+                        for (int cc = 0; cc < 12; ++cc)
+                            if (cf[cc] != 0.f) atomicAdd(gp + (size_t)of[cc] * TT_C + i, qv * cf[cc]);
                     }
                 }
             }
@@ -470,18 +491,23 @@ __global__ __launch_bounds__(256, 1) void k_render_bwd_tex(BwdTexParams p) {
             }
         }
         // ---- dV2 += k2bar k1^T ----
-        stage_rows<64>(Xs, k2, i, hi);
-        stage_rows<64>(Ys, k1, i, hi);
-        wgrad<64, 64>(accV2, Xs, Ys, i, hi);
+        const bool do_wgrad = !(cfg.flags & TT_DBG_NO_WGRAD);
+        if (do_wgrad) {
+            stage_rows<64>(Xs, k2, i, hi);
+            stage_rows<64>(Ys, k1, i, hi);
+            wgrad<64, 64>(accV2, Xs, Ys, i, hi);
+        }
         // ---- k1bar = n1 . (V2^T k2bar) ----
         float kb1[32];
         mv_bwd<64, 64>(Lt + TV2, k2, kb1, i, hi);
 #pragma unroll
         for (int r = 0; r < 32; ++r) kb1[r] = k1[r] > 0.f ? kb1[r] : 0.f;
         // ---- dV1 += k1bar e^T ----
-        stage_rows<64>(Xs, kb1, i, hi);
-        stage_rows<96>(Ys, e, i, hi);
-        wgrad<64, 96>(accV1, Xs, Ys, i, hi);
+        if (do_wgrad) {
+            stage_rows<64>(Xs, kb1, i, hi);
+            stage_rows<96>(Ys, e, i, hi);
+            wgrad<64, 96>(accV1, Xs, Ys, i, hi);
+        }
         // ---- ebar = V1^T k1bar ; scatter texel(3+p, c)[ch] += w_c * ebar[32p + ch] ----
         float eb[48];
         mv_bwd<96, 64>(Lt + TV1, kb1, eb, i, hi);
@@ -503,14 +529,28 @@ __global__ __launch_bounds__(256, 1) void k_render_bwd_tex(BwdTexParams p) {
                 }
             }
         }
-#pragma nounroll
-        for (int it = 0; it < 192; ++it) {
-            const int kk = 2 * it + hi;
-            const int s = kk / 12, cc = kk - s * 12;
-            const float coef = Cs[s * 12 + cc];
-            if (coef != 0.f) {
-                const float val = Es[s * 97 + (cc >> 2) * 32 + i] * coef;
-                atomicAdd(p.grad_packed + (size_t)Os[s * 12 + cc] * TT_C + i, val);
+        if (!(cfg.flags & TT_DBG_NO_SCATTER)) {
+#pragma unroll 2
+            for (int it = 0; it < 16; ++it) {
+                const int s = 2 * it + hi;
+                float ev[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) ev[pl] = Es[s * 97 + pl * 32 + i];
+                float cf[12];
+                int of[12];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(Cs + s * 12 + 4 * g);
+                    const i32x4 o4 = *reinterpret_cast<const i32x4*>(Os + s * 12 + 4 * g);
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        cf[4 * g + e2] = c4[e2];
+                        of[4 * g + e2] = o4[e2];
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < 12; ++cc)
+                    if (cf[cc] != 0.f) atomicAdd(p.grad_packed + (size_t)of[cc] * TT_C + i, ev[cc >> 2] * cf[cc]);
             }
         }
     }
@@ -544,6 +584,11 @@ static MlpGradPtrs to_gptrs(const tt_mlp_grads* g) {
     return m;
 }
 
+static int debug_flags() {
+    const char* e = getenv("TT_DEBUG_FLAGS");  // profiling ablations only
+    return e ? (int)strtol(e, nullptr, 0) : 0;
+}
+
 static long long persistent_blocks(long long work_items_per_wave_granule) {
     int cus = tt_num_cus();
     if (cus <= 0) return -1;
@@ -575,6 +620,7 @@ extern "C" int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, c
     p.t_starts = t_starts;
     p.t_ends = t_ends;
     p.cfg = *cfg;
+    p.cfg.flags |= debug_flags();
     p.opacity = opacity;
     p.depth = depth;
     p.trans = trans;
@@ -614,6 +660,7 @@ extern "C" int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, c
     p.t_starts = t_starts;
     p.t_ends = t_ends;
     p.cfg = *cfg;
+    p.cfg.flags |= debug_flags();
     p.weights = weights;
     p.features = features;
     p.g_rgb = g_rgb_fg;

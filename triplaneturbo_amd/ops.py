@@ -16,6 +16,47 @@ from . import _lib
 Tensor = torch.Tensor
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on torch's current stream (the stream every kernel of this
+    package is launched on).  bench.py uses it to report the dominant kernel's average duration."""
+
+    def __init__(self):
+        self.events = []  # (label, start, end)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        acc = {}
+        for label, a, b in self.events:
+            acc.setdefault(label, []).append(a.elapsed_time(b))
+        return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+_TIMER: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(t: Optional[KernelTimer]) -> None:
+    global _TIMER
+    _TIMER = t
+
+
+class _timed:
+    def __init__(self, label):
+        self.label = label
+
+    def __enter__(self):
+        if _TIMER is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMER is not None:
+            self.b.record()
+            _TIMER.events.append((self.label, self.a, self.b))
+        return False
+
+
 def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
     if t is None:
         return ctypes.c_void_p(0)
@@ -133,11 +174,12 @@ def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
     if per_sample:
         out.update(sdf=torch.empty((n_rays * S, 1), **f32), sdf_grad=torch.empty((n_rays * S, 3), **f32),
                    features=torch.empty((n_rays * S, 3), **f32))
-    st = _lib.load().tt_render_fwd(
-        _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends), ctypes.byref(cfg),
-        _ptr(out["opacity"]), _ptr(out["depth"]), _ptr(out["rgb_fg"]), _ptr(out["z_variance"]),
-        _ptr(out["normal_acc"]), _ptr(out["weights"]), _ptr(out["trans"]), _ptr(out.get("sdf")),
-        _ptr(out.get("sdf_grad")), _ptr(out.get("features")), _stream())
+    with _timed("k_render_fwd"):
+        st = _lib.load().tt_render_fwd(
+            _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
+            ctypes.byref(cfg), _ptr(out["opacity"]), _ptr(out["depth"]), _ptr(out["rgb_fg"]),
+            _ptr(out["z_variance"]), _ptr(out["normal_acc"]), _ptr(out["weights"]), _ptr(out["trans"]),
+            _ptr(out.get("sdf")), _ptr(out.get("sdf_grad")), _ptr(out.get("features")), _stream())
     _lib.check(st, "tt_render_fwd")
     return out
 
@@ -183,16 +225,18 @@ class _TriplaneRenderFn(torch.autograd.Function):
         g_op, g_depth, g_rgb, g_zvar, g_nacc = c(g_op), c(g_depth), c(g_rgb), c(g_zvar), c(g_nacc)
         g_weights, g_sdf, g_sdf_grad, g_features = c(g_weights), c(g_sdf), c(g_sdf_grad), c(g_features)
         lib = _lib.load()
-        st = lib.tt_render_bwd_geo(
-            _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
-            ctypes.byref(cfg), _ptr(opacity), _ptr(depth), _ptr(trans), _ptr(features), _ptr(g_op), _ptr(g_depth),
-            _ptr(g_rgb), _ptr(g_zvar), _ptr(g_nacc), _ptr(g_weights), _ptr(g_sdf), _ptr(g_sdf_grad),
-            _ptr(grad_packed), ctypes.byref(gst), _stream())
+        with _timed("k_render_bwd_geo"):
+            st = lib.tt_render_bwd_geo(
+                _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
+                ctypes.byref(cfg), _ptr(opacity), _ptr(depth), _ptr(trans), _ptr(features), _ptr(g_op),
+                _ptr(g_depth), _ptr(g_rgb), _ptr(g_zvar), _ptr(g_nacc), _ptr(g_weights), _ptr(g_sdf),
+                _ptr(g_sdf_grad), _ptr(grad_packed), ctypes.byref(gst), _stream())
         _lib.check(st, "tt_render_bwd_geo")
-        st = lib.tt_render_bwd_tex(
-            _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
-            ctypes.byref(cfg), _ptr(weights), _ptr(features), _ptr(g_rgb), _ptr(g_features), _ptr(grad_packed),
-            ctypes.byref(gst), _stream())
+        with _timed("k_render_bwd_tex"):
+            st = lib.tt_render_bwd_tex(
+                _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
+                ctypes.byref(cfg), _ptr(weights), _ptr(features), _ptr(g_rgb), _ptr(g_features),
+                _ptr(grad_packed), ctypes.byref(gst), _stream())
         _lib.check(st, "tt_render_bwd_tex")
         g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
         return (g_cache, *gw, None, None, None, None, None, None)
