@@ -171,7 +171,7 @@ def main():
     if rank == 0:
         ksum = timer.summary()  # label -> (avg ms, launches)
         n_samples = n_rays * S
-        flops = {"k_render_fwd": FLOP_FWD, "k_render_bwd_geo": FLOP_BWD_GEO, "k_render_bwd_tex": FLOP_BWD_TEX}
+        flops = {"tt_render_fwd": FLOP_FWD, "tt_render_bwd_geo": FLOP_BWD_GEO, "tt_render_bwd_tex": FLOP_BWD_TEX}
         kernels = {}
         for k, (ms, n) in ksum.items():
             kernels[k] = {"avg_ms": round(ms, 4), "launches": n,

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 1
+#define TT_ABI_VERSION 2
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -83,6 +83,8 @@ typedef struct {
     float cos_anneal_ratio;    /* neus_volume_renderer.py:101-104 */
     float rgb_grad_shrink;     /* renderer :397-400 (backward only) */
     int32_t flags;             /* TT_R_* */
+    int32_t image_w;           /* rays of a view form an image_w x (rays_per_view/image_w) image (8x4 pixel tiles);
+                                  0 = unknown: tiles are 32 consecutive rays */
 } tt_render_cfg;
 
 #define TT_R_PER_SAMPLE 1 /* also write per-sample sdf / sdf_grad / features (training extras, renderer :532-545) */
@@ -113,8 +115,9 @@ int tt_query_points(const float* packed, const tt_mlp_weights* w, const float* p
  * rays_o, rays_d (n_rays,3); t_starts, t_ends (n_rays,S).
  * Per-ray outputs: opacity (n_rays), depth (n_rays), rgb_fg (n_rays,3), z_variance (n_rays),
  *                  normal_acc (n_rays,3) = sum_i w_i n_i (NOT normalised).
- * Per-sample outputs (n_rays*S): weights, trans (always written; trans is saved for backward);
- *   sdf, sdf_grad (.,3), features (.,3) written when TT_R_PER_SAMPLE (may be null otherwise). */
+ * Per-sample outputs (n_rays*S), all required: weights, trans, sdf, sdf_grad (.,3), features (.,3).  The decode
+ *   kernel writes sdf/sdf_grad/features, the march kernel reads them back (they are also the renderer's
+ *   training extras, renderer :532-545, and the saved state of the backward). */
 int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
                   const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, float* opacity, float* depth,
                   float* rgb_fg, float* z_variance, float* normal_acc, float* weights, float* trans, float* sdf,
@@ -123,14 +126,16 @@ int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const float* ray
 /* Backward, geometry half: d/d(geometry planes 0..2) and d/d(sdf net).
  * Per-ray upstream grads (any may be null = 0): g_opacity, g_depth, g_rgb_fg(3), g_z_variance, g_normal_acc(3).
  * Per-sample upstream grads (null = 0): g_weights, g_sdf, g_sdf_grad(3).
- * Saved forward state: opacity, depth (per ray), trans, features (per sample).
+ * Saved forward state: opacity, depth (per ray), trans, sdf, sdf_grad, features (per sample).
+ * workspace: n_rays*S*4 floats (written by the march backward, read by the decode backward).
  * grad_packed (P,6,H,W,32) and mlp grads are accumulated into (caller zero-fills). */
 int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
                       const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, const float* opacity,
-                      const float* depth, const float* trans, const float* features, const float* g_opacity,
-                      const float* g_depth, const float* g_rgb_fg, const float* g_z_variance,
-                      const float* g_normal_acc, const float* g_weights, const float* g_sdf, const float* g_sdf_grad,
-                      float* grad_packed, const tt_mlp_grads* grads, void* stream);
+                      const float* depth, const float* trans, const float* sdf, const float* sdf_grad,
+                      const float* features, const float* g_opacity, const float* g_depth, const float* g_rgb_fg,
+                      const float* g_z_variance, const float* g_normal_acc, const float* g_weights,
+                      const float* g_sdf, const float* g_sdf_grad, float* workspace, float* grad_packed,
+                      const tt_mlp_grads* grads, void* stream);
 
 /* Backward, texture half: d/d(texture planes 3..5) and d/d(feature net).
  * Needs saved weights (per sample) and features; g_rgb_fg (per ray), g_features (per sample; null = 0). */

@@ -116,6 +116,37 @@ def test_backward_matches_oracle(mods, P, R, n_view, Hh, Ww, S, seed):
     print(_check(g_hip, g32, g64))
 
 
+@pytest.mark.parametrize("chunk,blocked", [(1, True), (7, True), (64, True), (5, False)])
+def test_every_tiling_matches_oracle(mods, chunk, blocked, monkeypatch):
+    """The per-sample kernels tile the (ray, sample) space as 8x4-pixel ray blocks (or 32-ray strips when the image
+    width is unknown) x chunks of sample indices; TT_CHUNK forces the chunk length.  Every tiling must reproduce
+    the oracle (forward outputs and all gradients), incl. ragged image edges (5x7 rays) and ragged chunks."""
+    monkeypatch.setenv("TT_CHUNK", str(chunk))
+    ops, functional = mods
+    P, R, n_view, Hh, Ww, S, seed = 2, 32, 2, 5, 7, 45, 21
+    g = torch.Generator().manual_seed(seed)
+    cache = torch.randn(P, 6, 32, R, R, generator=g) * 0.5
+    sw = O.init_mlp_weights([32, 64, 64, 1], g)
+    fw = O.init_mlp_weights([96, 64, 64, 3], g)
+    ro, rd, c2w, cd = O.make_cameras(P * n_view, Hh, Ww)
+    n_rays = P * n_view * Hh * Ww
+    ts, te = O.uniform_intervals(n_rays, S, 0.3, 3.2)
+    bg = torch.ones(3)
+    proj = {n: torch.randn(P * n_view, Hh, Ww, c, generator=g) for n, c in KEYS}
+    rck = dict(inv_std=100.0, rgb_grad_shrink=0.7, cos_anneal_ratio=1.0)
+    if not blocked:  # hide the image width from the kernels -> linear 32-ray strips
+        orig = ops.render_samples
+        monkeypatch.setattr(ops, "render_samples", lambda *a, image_w=0, **k: orig(*a, image_w=0, **k))
+    out, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    o32, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    o64, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    for key in ("comp_rgb", "opacity", "depth", "z_variance", "weights", "sdf", "features"):
+        e_hip = (out[key].detach().cpu().double() - o64[key].detach()).abs().max().item()
+        e_cpu = (o32[key].detach().double() - o64[key].detach()).abs().max().item()
+        assert e_hip <= max(4 * e_cpu, 2e-5), (key, e_hip, e_cpu)
+    _check(g_hip, g32, g64)
+
+
 def test_backward_is_linear_in_rays(mods):
     """Size-independent property used at full size: d loss/d(planes, weights) of a sum over rays equals the sum of
     the per-chunk gradients (the kernels accumulate with atomics; nothing may be dropped or double counted)."""

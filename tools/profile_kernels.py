@@ -24,9 +24,10 @@ def step():
     bench.loss_fn(out, inp["proj"]).backward()
 
 
-for name, flags in (("full", "0"), ("no_scatter", "0x100"), ("no_wgrad", "0x200"), ("no_scatter_no_wgrad", "0x300")):
-    if len(sys.argv) > 2 and sys.argv[2] == "fullonly" and name != "full":
-        continue
+variants = (("full", "0"), ("no_scatter", "0x100"), ("no_wgrad", "0x200"), ("no_scatter_no_wgrad", "0x300"))
+if len(sys.argv) > 2:  # explicit list of flag values, e.g. 0 0x2000 0x4000
+    variants = tuple((f, f) for f in sys.argv[2:])
+for name, flags in variants:
     os.environ["TT_DEBUG_FLAGS"] = flags
     step()
     t = ops.KernelTimer()

@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libtt_hip.so")
-SOURCES = ["tt_forward.hip", "tt_backward.hip", "tt_grad2.hip", "tt_host.cpp"]
+SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_grad2.hip", "tt_host.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared", "-fno-gpu-rdc"]
 
 # every symbol include/tt_abi.h declares (tests check the header and this list agree)
@@ -73,7 +73,7 @@ class RenderCfg(ctypes.Structure):
         ("n_prompts", _I32), ("views_per_prompt", _I32), ("plane_h", _I32), ("plane_w", _I32),
         ("rays_per_view", _I32), ("n_samples", _I32), ("n_rays", _I64), ("radius", _F),
         ("sdf_bias_radius", _F), ("inv_std", _F), ("cos_anneal_ratio", _F), ("rgb_grad_shrink", _F),
-        ("flags", _I32),
+        ("flags", _I32), ("image_w", _I32),
     ]
 
 
@@ -104,7 +104,7 @@ def load() -> ctypes.CDLL:
     lib.tt_render_fwd.argtypes = [_P, ctypes.POINTER(MlpWeights), _P, _P, _P, _P, ctypes.POINTER(RenderCfg)] + [_P] * 11
     _cfgp, _wp = ctypes.POINTER(RenderCfg), ctypes.POINTER(MlpWeights)
     optional = {
-        "tt_render_bwd_geo": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 12 + [_P, _wp, _P],
+        "tt_render_bwd_geo": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 14 + [_P, _P, _wp, _P],
         "tt_render_bwd_tex": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 4 + [_P, _wp, _P],
         "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 5 + [_P] * 3 + [_P],
     }

@@ -21,6 +21,15 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// profiling-only ablations, set through the TT_DEBUG_FLAGS env var (results are then WRONG by construction)
+#define TT_DBG_NO_SCATTER 0x100
+#define TT_DBG_NO_WGRAD 0x200
+#define TT_DBG_NO_GATHER 0x400
+#define TT_DBG_NO_MLP 0x800
+#define TT_DBG_NO_STORE 0x1000
+#define TT_DBG_NO_COMBINE 0x2000
+#define TT_DBG_NO_GLOBAL_ATOMIC 0x4000
+
 #define TT_C 32
 #define TT_HID 64
 #define TT_TILE 32
@@ -94,16 +103,17 @@ __device__ __forceinline__ void mv_fwd(const float* Wl, const float (&x)[NIN / 2
 }
 
 // y[NOUT] = W[NIN][NOUT]^T * x[NIN]   (W in LDS as stored, row stride NOUT+4).
-template <int NOUT, int NIN>
+// STRIDE != NOUT+4 selects a 32m-column slice of a wider stored matrix (Wl already offset to its first column).
+template <int NOUT, int NIN, int STRIDE = NOUT + 4>
 __device__ __forceinline__ void mv_bwd(const float* Wl, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i,
                                        int hi) {
-    const float* base = Wl + 4 * hi * (NOUT + 4) + i;
+    const float* base = Wl + 4 * hi * STRIDE + i;
 #pragma unroll
     for (int m = 0; m < NOUT / 32; ++m) {
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < NIN / 2; ++r) {
-            float a = base[LIDX(r, 0) * (NOUT + 4) + 32 * m];
+            float a = base[LIDX(r, 0) * STRIDE + 32 * m];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[r], acc, 0, 0, 0);
         }
 #pragma unroll
@@ -132,6 +142,7 @@ struct Corners {
     float w[4];   // bilinear weights nw, ne, sw, se (0 when out of bounds)
     float du[4];  // d w / d ix   (0 when out of bounds)
     float dv[4];  // d w / d iy
+    int hs[4];    // 8x8 torus hash of the texel (y&7)*8 + (x&7): slot in the write-combining window
     bool any;     // any corner in bounds
 };
 
@@ -164,6 +175,10 @@ __device__ __forceinline__ void corners_setup(float gx, float gy, int H, int W, 
     c.off[1] = in1 ? y0 * W + x0 + 1 : 0;
     c.off[2] = in2 ? (y0 + 1) * W + x0 : 0;
     c.off[3] = in3 ? (y0 + 1) * W + x0 + 1 : 0;
+    c.hs[0] = ((y0 & 7) << 3) | (x0 & 7);
+    c.hs[1] = ((y0 & 7) << 3) | ((x0 + 1) & 7);
+    c.hs[2] = (((y0 + 1) & 7) << 3) | (x0 & 7);
+    c.hs[3] = (((y0 + 1) & 7) << 3) | ((x0 + 1) & 7);
     c.any = in0 || in1 || in2 || in3;
 }
 
@@ -197,7 +212,7 @@ __device__ __forceinline__ float sphere_bias(float px, float py, float pz, float
 template <bool NEED_J>
 __device__ __forceinline__ bool gather_geo(const float* __restrict__ planes, int H, int W, float X, float Y, float Z,
                                            bool valid, float jscale_u, float jscale_v, int hi, float (&f)[16],
-                                           float (&jx)[16], float (&jy)[16], float (&jz)[16]) {
+                                           float (&jx)[16], float (&jy)[16], float (&jz)[16], int dbg = 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         f[r] = 0.f;
@@ -216,7 +231,16 @@ __device__ __forceinline__ bool gather_geo(const float* __restrict__ planes, int
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const f32x4* t = reinterpret_cast<const f32x4*>(planes + (p * HW + (size_t)c.off[k]) * TT_C) + hi;
-            f32x4 v[4] = {t[0], t[2], t[4], t[6]};
+            f32x4 v[4];
+            if (dbg & TT_DBG_NO_GATHER) {
+                const f32x4 z = {c.w[k], c.du[k], c.dv[k], X};
+                v[0] = v[1] = v[2] = v[3] = z;
+            } else {
+                v[0] = t[0];
+                v[1] = t[2];
+                v[2] = t[4];
+                v[3] = t[6];
+            }
             const float wk = c.w[k], a = c.du[k] * jscale_u, b = c.dv[k] * jscale_v;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -244,7 +268,7 @@ __device__ __forceinline__ bool gather_geo(const float* __restrict__ planes, int
 
 // texture planes (v2 = concat over planes): e[48], e[16p + r] <-> channel LIDX(r,hi) of plane p
 __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int H, int W, float X, float Y, float Z,
-                                           bool valid, int hi, float (&e)[48]) {
+                                           bool valid, int hi, float (&e)[48], int dbg = 0) {
 #pragma unroll
     for (int r = 0; r < 48; ++r) e[r] = 0.f;
     bool any = false;
@@ -258,7 +282,16 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const f32x4* t = reinterpret_cast<const f32x4*>(planes + ((3 + p) * HW + (size_t)c.off[k]) * TT_C) + hi;
-            f32x4 v[4] = {t[0], t[2], t[4], t[6]};
+            f32x4 v[4];
+            if (dbg & TT_DBG_NO_GATHER) {
+                const f32x4 z = {c.w[k], Y, Z, X};
+                v[0] = v[1] = v[2] = v[3] = z;
+            } else {
+                v[0] = t[0];
+                v[1] = t[2];
+                v[2] = t[4];
+                v[3] = t[6];
+            }
             const float wk = c.w[k];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -269,27 +302,107 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
     return any;
 }
 
-// ---- wave scans over the 32 samples of a tile (both halves run the same scan redundantly) -----------
-__device__ __forceinline__ float half_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
+// ---- work decomposition of the per-sample kernels ----------------------------------------------------------
+// A TILE is 32 samples = 32 ADJACENT RAYS at the same sample index (an 8x4 pixel block when the image width is
+// known, else 32 consecutive rays): adjacent rays hit neighbouring texels at equal depth, so gathers hit L1 and
+// the plane-gradient scatter of a tile touches few distinct texels.  A WORK ITEM is (ray block, chunk of CH
+// consecutive sample indices); items are independent (the ray march is a separate kernel), so the grid is
+// balanced whatever the image size.  Block b runs on XCD b % 8 and every XCD owns one contiguous chunk of items
+// (its texels stay in that XCD's L2).
+struct ItemRange {
+    long long lo, hi;
+    int stride;
+};
+__device__ __forceinline__ ItemRange item_range(long long n_items) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long long chunk = (n_items + 7) / 8;
+    ItemRange g;
+    const long long lo = xcd * chunk;
+    g.hi = (lo + chunk < n_items) ? lo + chunk : n_items;
+    g.stride = (gridDim.x >> 3) * (blockDim.x >> 6);
+    g.lo = lo + slot * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    return g;
+}
+
+struct TileGeom {
+    long long n_rays;
+    int rays_per_view;
+    int image_w, image_h;  // image_w == 0: linear 32-ray strips
+    int bpr, bpv;          // 8x4 blocks per image row / per view
+    int n_samples, chunk, n_chunks;
+};
+
+// ray handled by lane j (0..31) of ray block b
+__device__ __forceinline__ long long tile_ray(const TileGeom& g, long long b, int j, bool& rvalid) {
+    long long ray;
+    if (g.image_w > 0) {
+        const long long view = b / g.bpv;
+        const int rem = (int)(b - view * g.bpv);
+        const int by = rem / g.bpr, bx = rem - by * g.bpr;
+        const int x = bx * 8 + (j & 7), y = by * 4 + (j >> 3);
+        rvalid = x < g.image_w && y < g.image_h;
+        ray = view * g.rays_per_view + (long long)y * g.image_w + x;
+    } else {
+        ray = b * 32 + j;
+        rvalid = true;
+    }
+    rvalid = rvalid && ray < g.n_rays;
+    return rvalid ? ray : g.n_rays - 1;
+}
+
+// ---- tile layout and segmented wave scans -----------------------------------------------------------------
+// A 32-sample tile is RB rays x SB consecutive samples (RB*SB = 32).  Lane j = lane&31: ray rl = j / SB,
+// sample k = j % SB, so the SB samples of one ray sit in adjacent lanes and every scan below runs on
+// segments of SB lanes (width-SB shuffles).  SB = 32: one ray per tile; SB = 1: 32 adjacent rays marching in
+// lock-step (no scan at all).  Both half-waves run the same scans redundantly.
+template <int SB>
+__device__ __forceinline__ float seg_sum(float v) {
+#pragma unroll
+    for (int d = 1; d < SB; d <<= 1) v += __shfl_xor(v, d);
     return v;
 }
 
-// exclusive prefix product over lanes j = 0..31 of each half; total = product over the whole tile
-__device__ __forceinline__ float excl_prod32(float v, int j, float& total) {
+// exclusive prefix product over the SB lanes of a segment; total = product over the segment
+template <int SB>
+__device__ __forceinline__ float seg_excl_prod(float v, int k, float& total) {
+    if (SB == 1) {
+        total = v;
+        return 1.f;
+    }
     float inc = v;
 #pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        float o = __shfl_up(inc, d, 32);
-        if (j >= d) inc *= o;
+    for (int d = 1; d < SB; d <<= 1) {
+        float o = __shfl_up(inc, d, SB);
+        if (k >= d) inc *= o;
     }
-    total = __shfl(inc, 31, 32);
-    float ex = __shfl_up(inc, 1, 32);
-    return j == 0 ? 1.f : ex;
+    total = __shfl(inc, SB - 1, SB);
+    float ex = __shfl_up(inc, 1, SB);
+    return k == 0 ? 1.f : ex;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// Reverse affine scan for the backward of the transmittance product.  Per lane phi_k(x) = A x + B with
+// A = 1 - alpha_k, B = V_k alpha_k.  Returns R_{k+1} = (phi_{k+1} o ... o phi_{SB-1})(carry) for this lane and
+// updates carry to R_0 = (phi_0 o ... )(carry) of the segment.
+template <int SB>
+__device__ __forceinline__ float seg_rev_affine(float A_, float B_, int k, float& carry) {
+    if (SB == 1) {
+        const float rn = carry;
+        carry = fmaf(A_, carry, B_);
+        return rn;
+    }
+#pragma unroll
+    for (int d = 1; d < SB; d <<= 1) {
+        const float Ao = __shfl_down(A_, d, SB), Bo = __shfl_down(B_, d, SB);
+        if (k + d < SB) {
+            B_ = fmaf(A_, Bo, B_);
+            A_ *= Ao;
+        }
+    }
+    const float Ri = fmaf(A_, carry, B_);
+    float Rnext = __shfl_down(Ri, 1, SB);
+    if (k == SB - 1) Rnext = carry;
+    carry = __shfl(Ri, 0, SB);
+    return Rnext;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }

@@ -2,6 +2,8 @@
 #include "tt_device.h"
 #include "tt_host.h"
 
+#include <stdlib.h>
+
 // =====================================================================================================
 // plane pack: (P,6,32,H,W) NCHW  ->  (P,6,H,W,32) channels-last with rotate_planes "v1" folded in
 //   R0[h,w] = P0[w,h]   R1[h,w] = P1[H-1-h, W-1-w]   R2[h,w] = P2[H-1-w, h]   (few_step...:212-225)
@@ -66,6 +68,7 @@ struct DecodeCfg {
     int H, W;
     float radius;
     float ju, jv;  // 0.5*W/radius, 0.5*H/radius
+    int dbg;       // profiling-only ablation flags
 };
 
 // outputs are identical in both half-waves.  gq = J^T q (WITHOUT the sphere term).
@@ -78,8 +81,13 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
     c[0] = c[1] = c[2] = 0.f;
     if (NEED_TEX) {
         float e[48];
-        bool any = gather_tex(dc.pbase, dc.H, dc.W, X, Y, Z, valid, hi, e);
-        if (__any(any)) {  // exact skip: e == 0 for the whole tile => features == 0 (bias-free MLP)
+        bool any = gather_tex(dc.pbase, dc.H, dc.W, X, Y, Z, valid, hi, e, dc.dbg);
+        if (dc.dbg & TT_DBG_NO_MLP) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 48; ++r) t += e[r];
+            c[0] = c[1] = c[2] = t;
+        } else if (__any(any)) {  // exact skip: e == 0 for the whole tile => features == 0 (bias-free MLP)
             float k1[32], k2[32];
             mv_fwd<64, 96>(L + OFF_V1, e, k1, i, hi);
 #pragma unroll
@@ -93,8 +101,21 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
     }
     {
         float f[16], jx[16], jy[16], jz[16];
-        bool any = gather_geo<NEED_N>(dc.pbase, dc.H, dc.W, X, Y, Z, valid, dc.ju, dc.jv, hi, f, jx, jy, jz);
-        if (__any(any)) {
+        bool any = gather_geo<NEED_N>(dc.pbase, dc.H, dc.W, X, Y, Z, valid, dc.ju, dc.jv, hi, f, jx, jy, jz, dc.dbg);
+        if (dc.dbg & TT_DBG_NO_MLP) {
+            float t = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                t += f[r];
+                tx += jx[r];
+                ty += jy[r];
+                tz += jz[r];
+            }
+            s0 = t;
+            gq[0] = tx;
+            gq[1] = ty;
+            gq[2] = tz;
+        } else if (__any(any)) {
             float h1[32], h2[32];
             mv_fwd<64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
@@ -174,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void k_query_points(QueryParams p) {
         dc.radius = p.radius;
         dc.ju = 0.5f * p.W / p.radius;
         dc.jv = 0.5f * p.H / p.radius;
+        dc.dbg = 0;
         const float px = p.points[idx * 3 + 0], py = p.points[idx * 3 + 1], pz = p.points[idx * 3 + 2];
         float s0, gq[3], c[3];
         decode_fwd<NEED_N, NEED_TEX>(L, dc, px, py, pz, valid, i, hi, s0, gq, c);
@@ -196,9 +218,9 @@ __global__ __launch_bounds__(256, 2) void k_query_points(QueryParams p) {
 }
 
 // =====================================================================================================
-// fused forward render: one wave per ray, 32 samples per tile
+// K1: decode every sample of every ray (tiles of 32 adjacent rays x one sample index, chunks of CH indices)
 // =====================================================================================================
-struct RenderFwdParams {
+struct DecodeRaysParams {
     const float* packed;
     MlpPtrs w;
     const float* rays_o;
@@ -206,55 +228,35 @@ struct RenderFwdParams {
     const float* t_starts;
     const float* t_ends;
     tt_render_cfg cfg;
-    float* opacity;
-    float* depth;
-    float* rgb_fg;
-    float* z_var;
-    float* nacc;
-    float* weights;
-    float* trans;
+    TileGeom geom;
+    long long n_items;
     float* sdf;
     float* sdf_grad;
     float* features;
 };
 
-__device__ __forceinline__ float neus_alpha(float sdf, float cosv, float dt, float inv_std, float ratio) {
-    // neus_volume_renderer.py:98-116
-    const float iter_cos = -(fmaxf(-cosv * 0.5f + 0.5f, 0.f) * (1.f - ratio) + fmaxf(-cosv, 0.f) * ratio);
-    const float next_sdf = sdf + iter_cos * dt * 0.5f;
-    const float prev_sdf = sdf - iter_cos * dt * 0.5f;
-    const float prev_cdf = sigmoidf_(prev_sdf * inv_std);
-    const float next_cdf = sigmoidf_(next_sdf * inv_std);
-    const float pp = prev_cdf - next_cdf;
-    const float a = (pp + 1e-5f) / (prev_cdf + 1e-5f);
-    return fminf(fmaxf(a, 0.f), 1.f);
-}
-
-__global__ __launch_bounds__(256, 2) void k_render_fwd(RenderFwdParams p) {
+template <bool NEED_N, bool NEED_TEX>
+__global__ __launch_bounds__(256, 2) void k_decode_rays(DecodeRaysParams p) {
     __shared__ __attribute__((aligned(16))) float L[LDS_W_FLOATS];
     {
         MlpPtrs w = p.w;
         lds_load_geo_weights(L, w);
-        lds_load_tex_weights(L, w);
+        if (NEED_TEX) lds_load_tex_weights(L, w);
     }
     __syncthreads();
     const tt_render_cfg& cfg = p.cfg;
+    const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const int S = cfg.n_samples;
-    const int n_tiles = (S + TT_TILE - 1) / TT_TILE;
-    // XCD-aware ray assignment: block b runs on XCD b % 8; give each XCD one contiguous chunk of rays so the
-    // texels its waves touch stay in that XCD's L2.
-    const long long n_rays = cfg.n_rays;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const long long chunk = (n_rays + 7) / 8;
-    const long long lo = xcd * chunk, hiR = (lo + chunk < n_rays) ? lo + chunk : n_rays;
-    const int waves_per_xcd = (gridDim.x >> 3) * (blockDim.x >> 6);
-    const int wv = slot * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const ItemRange ir = item_range(p.n_items);
     const size_t plane_stride = (size_t)6 * cfg.plane_h * cfg.plane_w * TT_C;
-    const bool per_sample = (cfg.flags & TT_R_PER_SAMPLE) != 0;
 
 #pragma nounroll
-    for (long long ray = lo + wv; ray < hiR; ray += waves_per_xcd) {
+    for (long long item = ir.lo; item < ir.hi; item += ir.stride) {
+        const long long b = item / tg.n_chunks;
+        const int ck = (int)(item - b * tg.n_chunks);
+        bool rvalid;
+        const long long ray = tile_ray(tg, b, i, rvalid);
         const int view = (int)(ray / cfg.rays_per_view);
         DecodeCfg dc;
         dc.pbase = p.packed + (size_t)(view / cfg.views_per_prompt) * plane_stride;
@@ -263,91 +265,33 @@ __global__ __launch_bounds__(256, 2) void k_render_fwd(RenderFwdParams p) {
         dc.radius = cfg.radius;
         dc.ju = 0.5f * cfg.plane_w / cfg.radius;
         dc.jv = 0.5f * cfg.plane_h / cfg.radius;
+        dc.dbg = cfg.flags;
         const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
         const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
-        float T = 1.f;
-        float a_op = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_nx = 0.f, a_ny = 0.f, a_nz = 0.f;
+        const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
 #pragma nounroll
-        for (int tile = 0; tile < n_tiles; ++tile) {
-            const int si = tile * TT_TILE + i;
-            const bool valid = si < S;
-            const long long sidx = ray * S + (valid ? si : 0);
-            const float ts = valid ? p.t_starts[sidx] : 0.f, te = valid ? p.t_ends[sidx] : 0.f;
+        for (int si = ck * tg.chunk; si < s_end; ++si) {
+            const long long sidx = ray * S + si;
+            const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
             float tm, px, py, pz;
             sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
             float s0, gq[3], c[3];
-            decode_fwd<true, true>(L, dc, px, py, pz, valid, i, hi, s0, gq, c);
+            decode_fwd<NEED_N, NEED_TEX>(L, dc, px, py, pz, rvalid, i, hi, s0, gq, c);
             float nrm;
             const float sdf = s0 + sphere_bias(px, py, pz, cfg.sdf_bias_radius, nrm);
-            const float gx = gq[0] + px / nrm, gy = gq[1] + py / nrm, gz = gq[2] + pz / nrm;
-            const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps
-            const float nx = gx / gn, ny = gy / gn, nz = gz / gn;
-            const float cosv = dx * nx + dy * ny + dz * nz;
-            float alpha = neus_alpha(sdf, cosv, te - ts, cfg.inv_std, cfg.cos_anneal_ratio);
-            if (!valid) alpha = 0.f;
-            float total;
-            const float Ti = T * excl_prod32(1.f - alpha, i, total);
-            T *= total;
-            const float wgt = alpha * Ti;
-            // NoMaterial + sigmoid-mipnerf (no_material.py:41-54, ops.py:118-119)
-            const float r = sigmoidf_(c[0]) * 1.002f - 0.001f, g = sigmoidf_(c[1]) * 1.002f - 0.001f,
-                        b = sigmoidf_(c[2]) * 1.002f - 0.001f;
-            a_op += wgt;
-            a_d = fmaf(wgt, tm, a_d);
-            a_r = fmaf(wgt, r, a_r);
-            a_g = fmaf(wgt, g, a_g);
-            a_b = fmaf(wgt, b, a_b);
-            a_nx = fmaf(wgt, nx, a_nx);
-            a_ny = fmaf(wgt, ny, a_ny);
-            a_nz = fmaf(wgt, nz, a_nz);
-            if (valid && hi == 0) {
-                p.weights[sidx] = wgt;
-                p.trans[sidx] = Ti;
-                if (per_sample) {
-                    if (p.sdf) p.sdf[sidx] = sdf;
-                    if (p.sdf_grad) {
-                        p.sdf_grad[sidx * 3 + 0] = gx;
-                        p.sdf_grad[sidx * 3 + 1] = gy;
-                        p.sdf_grad[sidx * 3 + 2] = gz;
-                    }
-                    if (p.features) {
-                        p.features[sidx * 3 + 0] = c[0];
-                        p.features[sidx * 3 + 1] = c[1];
-                        p.features[sidx * 3 + 2] = c[2];
-                    }
+            if (rvalid && hi == 0 && !(cfg.flags & TT_DBG_NO_STORE)) {
+                p.sdf[sidx] = sdf;
+                if (NEED_N) {
+                    p.sdf_grad[sidx * 3 + 0] = gq[0] + px / nrm;
+                    p.sdf_grad[sidx * 3 + 1] = gq[1] + py / nrm;
+                    p.sdf_grad[sidx * 3 + 2] = gq[2] + pz / nrm;
+                }
+                if (NEED_TEX) {
+                    p.features[sidx * 3 + 0] = c[0];
+                    p.features[sidx * 3 + 1] = c[1];
+                    p.features[sidx * 3 + 2] = c[2];
                 }
             }
-        }
-        a_op = half_sum(a_op);
-        a_d = half_sum(a_d);
-        a_r = half_sum(a_r);
-        a_g = half_sum(a_g);
-        a_b = half_sum(a_b);
-        a_nx = half_sum(a_nx);
-        a_ny = half_sum(a_ny);
-        a_nz = half_sum(a_nz);
-        // z_variance = sum w (t - depth)^2 (renderer :424-431): second pass over this lane's own weights
-        float zv = 0.f;
-        for (int tile = 0; tile < n_tiles; ++tile) {
-            const int si = tile * TT_TILE + i;
-            if (si < S && hi == 0) {
-                const long long sidx = ray * S + si;
-                const float tm = (p.t_starts[sidx] + p.t_ends[sidx]) / 2.f;
-                const float dd = tm - a_d;
-                zv = fmaf(p.weights[sidx], dd * dd, zv);
-            }
-        }
-        zv = half_sum(zv);
-        if (lane == 0) {
-            p.opacity[ray] = a_op;
-            p.depth[ray] = a_d;
-            p.rgb_fg[ray * 3 + 0] = a_r;
-            p.rgb_fg[ray * 3 + 1] = a_g;
-            p.rgb_fg[ray * 3 + 2] = a_b;
-            p.z_var[ray] = zv;
-            p.nacc[ray * 3 + 0] = a_nx;
-            p.nacc[ray * 3 + 1] = a_ny;
-            p.nacc[ray * 3 + 2] = a_nz;
         }
     }
 }
@@ -441,6 +385,42 @@ int tt_validate_cfg(const tt_render_cfg* cfg) {
     return TT_OK;
 }
 
+// Fills the tile geometry and picks the chunk length: enough items (>= 8 per wave slot) for balance, chunks as
+// long as possible so consecutive depths of the same rays reuse L1/L2-resident texels.
+long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g) {
+    g->n_rays = cfg->n_rays;
+    g->rays_per_view = cfg->rays_per_view;
+    g->n_samples = cfg->n_samples;
+    g->image_w = 0;
+    g->image_h = 0;
+    g->bpr = g->bpv = 0;
+    long long n_blocks;
+    if (cfg->image_w > 0 && cfg->rays_per_view % cfg->image_w == 0) {
+        g->image_w = cfg->image_w;
+        g->image_h = cfg->rays_per_view / cfg->image_w;
+        g->bpr = (g->image_w + 7) / 8;
+        g->bpv = g->bpr * ((g->image_h + 3) / 4);
+        n_blocks = (cfg->n_rays / cfg->rays_per_view) * g->bpv;
+    } else {
+        n_blocks = (cfg->n_rays + 31) / 32;
+    }
+    int n_chunks = (int)((8 * wave_slots + n_blocks - 1) / n_blocks);
+    if (n_chunks < 1) n_chunks = 1;
+    if (n_chunks > cfg->n_samples) n_chunks = cfg->n_samples;
+    if (const char* e = getenv("TT_CHUNK")) {  // tuning only
+        int c = atoi(e);
+        if (c > 0) n_chunks = (cfg->n_samples + c - 1) / c;
+    }
+    g->chunk = (cfg->n_samples + n_chunks - 1) / n_chunks;
+    g->n_chunks = (cfg->n_samples + g->chunk - 1) / g->chunk;
+    return n_blocks * g->n_chunks;
+}
+
+int tt_launch_march_fwd(const float* rays_d, const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,
+                        const float* sdf, const float* sdf_grad, const float* features, float* opacity, float* depth,
+                        float* rgb_fg, float* z_variance, float* normal_acc, float* weights, float* trans,
+                        hipStream_t stream);
+
 extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
                              const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, float* opacity,
                              float* depth, float* rgb_fg, float* z_variance, float* normal_acc, float* weights,
@@ -448,10 +428,12 @@ extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const
     int st = tt_validate_cfg(cfg);
     if (st != TT_OK) return st;
     if (!packed || !w || !rays_o || !rays_d || !t_starts || !t_ends || !opacity || !depth || !rgb_fg || !z_variance ||
-        !normal_acc || !weights || !trans)
+        !normal_acc || !weights || !trans || !sdf || !sdf_grad || !features)
         return TT_ERR_BAD_ARG;
     if (!w->w1 || !w->w2 || !w->w3 || !w->v1 || !w->v2 || !w->v3) return TT_ERR_BAD_ARG;
-    RenderFwdParams p;
+    int cus = tt_num_cus();
+    if (cus <= 0) return TT_ERR_DEVICE;
+    DecodeRaysParams p;
     p.packed = packed;
     p.w = to_ptrs(w);
     p.rays_o = rays_o;
@@ -459,22 +441,20 @@ extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const
     p.t_starts = t_starts;
     p.t_ends = t_ends;
     p.cfg = *cfg;
-    p.opacity = opacity;
-    p.depth = depth;
-    p.rgb_fg = rgb_fg;
-    p.z_var = z_variance;
-    p.nacc = normal_acc;
-    p.weights = weights;
-    p.trans = trans;
+    if (const char* e = getenv("TT_DEBUG_FLAGS")) p.cfg.flags |= (int)strtol(e, nullptr, 0);  // profiling only
     p.sdf = sdf;
     p.sdf_grad = sdf_grad;
     p.features = features;
-    int cus = tt_num_cus();
-    if (cus <= 0) return TT_ERR_DEVICE;
-    long long blocks = 2LL * cus;  // 2 workgroups of 4 waves per CU (LDS 69 KB each)
-    long long need = (cfg->n_rays + 3) / 4;
+    const long long slots = 2LL * cus * 4;  // 2 workgroups of 4 waves per CU (LDS 69 KB each)
+    p.n_items = tt_make_geom(cfg, slots, &p.geom);
+    long long blocks = 2LL * cus;
+    long long need = (p.n_items + 3) / 4;
     if (blocks > need) blocks = need;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_render_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    return tt_check_launch();
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((k_decode_rays<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    st = tt_check_launch();
+    if (st != TT_OK) return st;
+    return tt_launch_march_fwd(rays_d, t_starts, t_ends, cfg, sdf, sdf_grad, features, opacity, depth, rgb_fg,
+                               z_variance, normal_acc, weights, trans, s);
 }

@@ -1,6 +1,8 @@
 // tt_host.cpp -- status strings, launch checking, device queries (no global mutable state)
 #include "tt_host.h"
 
+#include <stdlib.h>
+
 extern "C" const char* tt_strerror(int status) {
     switch (status) {
         case TT_OK: return "ok";

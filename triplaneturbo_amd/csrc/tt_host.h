@@ -7,3 +7,7 @@
 int tt_check_launch();
 int tt_num_cus();
 int tt_validate_cfg(const tt_render_cfg* cfg);
+
+struct TileGeom;
+// fills the tile geometry / chunking for a render config; returns the number of work items
+long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g);

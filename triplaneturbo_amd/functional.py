@@ -24,7 +24,7 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
     S = t_starts.shape[1]
     ro = rays_o.reshape(n_rays, 3)
     rd = rays_d.reshape(n_rays, 3)
-    r = ops.render_samples(space_cache, sdf_w, feat_w, ro, rd, t_starts, t_ends, Hh * Ww, rc)
+    r = ops.render_samples(space_cache, sdf_w, feat_w, ro, rd, t_starts, t_ends, Hh * Ww, rc, image_w=Ww)
     opacity, depth, comp_rgb_fg, z_variance = r["opacity"], r["depth"], r["rgb_fg"], r["z_variance"]
 
     if bg_color.ndim == 1:

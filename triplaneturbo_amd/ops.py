@@ -140,7 +140,7 @@ def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Seque
 
 
 def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, rc: RenderConfig,
-              per_sample: bool) -> "_lib.RenderCfg":
+              per_sample: bool, image_w: int = 0) -> "_lib.RenderCfg":
     P, _, H, W, _ = packed.shape
     n_views = n_rays // rays_per_view
     if n_views * rays_per_view != n_rays or n_views % P != 0:
@@ -148,20 +148,22 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
     inv_std = min(max(float(rc.inv_std), 1.0e-6), 1.0e6)  # LearnedVariance.forward clamp, renderer :34-35
     return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
                           inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
-                          _lib.TT_R_PER_SAMPLE if per_sample else 0)
+                          _lib.TT_R_PER_SAMPLE if per_sample else 0,
+                          image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0)
 
 
 def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
                        rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, rays_per_view: int, rc: RenderConfig,
-                       per_sample: bool = True):
-    """One tt_render_fwd launch.  rays_* (n_rays,3); t_* (n_rays,S).  Returns a dict of raw kernel outputs."""
+                       per_sample: bool = True, image_w: int = 0):
+    """One tt_render_fwd call (decode kernel + march kernel).  rays_* (n_rays,3); t_* (n_rays,S); image_w = width
+    of each view's ray image (enables 8x4 pixel tiles).  Returns a dict of raw kernel outputs."""
     packed = _chk(packed, "packed")
     rays_o, rays_d = _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d")
     t_starts, t_ends = _chk(t_starts, "t_starts"), _chk(t_ends, "t_ends")
     n_rays, S = t_starts.shape
     if rays_o.shape != (n_rays, 3) or rays_d.shape != (n_rays, 3) or t_ends.shape != (n_rays, S):
         raise ValueError("ray / interval shapes disagree")
-    cfg = _make_cfg(packed, n_rays, rays_per_view, S, rc, per_sample)
+    cfg = _make_cfg(packed, n_rays, rays_per_view, S, rc, per_sample, image_w)
     wst, keep = _weights_struct(sdf_w, feat_w)
     dev = packed.device
     f32 = dict(device=dev, dtype=torch.float32)
@@ -171,10 +173,10 @@ def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
         "normal_acc": torch.empty((n_rays, 3), **f32),
         "weights": torch.empty((n_rays * S, 1), **f32), "trans": torch.empty((n_rays * S, 1), **f32),
     }
-    if per_sample:
-        out.update(sdf=torch.empty((n_rays * S, 1), **f32), sdf_grad=torch.empty((n_rays * S, 3), **f32),
-                   features=torch.empty((n_rays * S, 3), **f32))
-    with _timed("k_render_fwd"):
+    # per-sample decode results: outputs in training, inter-kernel workspace always
+    out.update(sdf=torch.empty((n_rays * S, 1), **f32), sdf_grad=torch.empty((n_rays * S, 3), **f32),
+               features=torch.empty((n_rays * S, 3), **f32))
+    with _timed("tt_render_fwd"):
         st = _lib.load().tt_render_fwd(
             _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
             ctypes.byref(cfg), _ptr(out["opacity"]), _ptr(out["depth"]), _ptr(out["rgb_fg"]),
@@ -194,16 +196,19 @@ class _TriplaneRenderFn(torch.autograd.Function):
     (sample positions are constants: the reference's sampler runs under no_grad, estimators.py:22)."""
 
     @staticmethod
-    def forward(ctx, space_cache, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, rays_per_view, rc):
+    def forward(ctx, space_cache, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, rays_per_view, rc,
+                image_w):
         packed = planes_pack(space_cache)
         need_grad = any(ctx.needs_input_grad[:7])
         raw = render_forward_raw(packed, (w1, w2, w3), (v1, v2, v3), rays_o, rays_d, t_starts, t_ends, rays_per_view,
-                                 rc, per_sample=True)
+                                 rc, per_sample=True, image_w=image_w)
         ctx.rays_per_view = rays_per_view
         ctx.rc = rc
+        ctx.image_w = image_w
         if need_grad:
             ctx.save_for_backward(packed, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, raw["opacity"],
-                                  raw["depth"], raw["trans"], raw["weights"], raw["features"])
+                                  raw["depth"], raw["trans"], raw["weights"], raw["features"], raw["sdf"],
+                                  raw["sdf_grad"])
         ctx.mark_non_differentiable(raw["trans"])
         return (raw["opacity"], raw["depth"], raw["rgb_fg"], raw["z_variance"], raw["normal_acc"], raw["weights"],
                 raw["sdf"], raw["sdf_grad"], raw["features"], raw["trans"])
@@ -211,9 +216,10 @@ class _TriplaneRenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_op, g_depth, g_rgb, g_zvar, g_nacc, g_weights, g_sdf, g_sdf_grad, g_features, _g_trans):
         (packed, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, opacity, depth, trans, weights,
-         features) = ctx.saved_tensors
+         features, sdf, sdf_grad) = ctx.saved_tensors
         n_rays, S = t_starts.shape
-        cfg = _make_cfg(packed, n_rays, ctx.rays_per_view, S, ctx.rc, True)
+        cfg = _make_cfg(packed, n_rays, ctx.rays_per_view, S, ctx.rc, True, ctx.image_w)
+        workspace = torch.empty((n_rays * S, 4), device=packed.device, dtype=torch.float32)
         wst, keep = _weights_struct((w1, w2, w3), (v1, v2, v3))
         grad_packed = torch.zeros_like(packed)
         gw = [torch.zeros_like(t) for t in (w1, w2, w3, v1, v2, v3)]
@@ -225,30 +231,31 @@ class _TriplaneRenderFn(torch.autograd.Function):
         g_op, g_depth, g_rgb, g_zvar, g_nacc = c(g_op), c(g_depth), c(g_rgb), c(g_zvar), c(g_nacc)
         g_weights, g_sdf, g_sdf_grad, g_features = c(g_weights), c(g_sdf), c(g_sdf_grad), c(g_features)
         lib = _lib.load()
-        with _timed("k_render_bwd_geo"):
+        with _timed("tt_render_bwd_geo"):
             st = lib.tt_render_bwd_geo(
                 _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
-                ctypes.byref(cfg), _ptr(opacity), _ptr(depth), _ptr(trans), _ptr(features), _ptr(g_op),
-                _ptr(g_depth), _ptr(g_rgb), _ptr(g_zvar), _ptr(g_nacc), _ptr(g_weights), _ptr(g_sdf),
-                _ptr(g_sdf_grad), _ptr(grad_packed), ctypes.byref(gst), _stream())
+                ctypes.byref(cfg), _ptr(opacity), _ptr(depth), _ptr(trans), _ptr(sdf), _ptr(sdf_grad),
+                _ptr(features), _ptr(g_op), _ptr(g_depth), _ptr(g_rgb), _ptr(g_zvar), _ptr(g_nacc), _ptr(g_weights),
+                _ptr(g_sdf), _ptr(g_sdf_grad), _ptr(workspace), _ptr(grad_packed), ctypes.byref(gst), _stream())
         _lib.check(st, "tt_render_bwd_geo")
-        with _timed("k_render_bwd_tex"):
+        with _timed("tt_render_bwd_tex"):
             st = lib.tt_render_bwd_tex(
                 _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
                 ctypes.byref(cfg), _ptr(weights), _ptr(features), _ptr(g_rgb), _ptr(g_features),
                 _ptr(grad_packed), ctypes.byref(gst), _stream())
         _lib.check(st, "tt_render_bwd_tex")
         g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
-        return (g_cache, *gw, None, None, None, None, None, None)
+        return (g_cache, *gw, None, None, None, None, None, None, None)
 
 
 def render_samples(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
-                   rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, rays_per_view: int, rc: RenderConfig):
-    """Differentiable fused render for explicit sample intervals.  Returns a dict of per-ray accumulators and
+                   rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, rays_per_view: int, rc: RenderConfig,
+                   image_w: int = 0):
+    """Differentiable render for explicit sample intervals.  Returns a dict of per-ray accumulators and
     per-sample tensors (autograd-connected to space_cache and the MLP weights)."""
     names = ("opacity", "depth", "rgb_fg", "z_variance", "normal_acc", "weights", "sdf", "sdf_grad", "features",
              "trans")
     outs = _TriplaneRenderFn.apply(space_cache, sdf_w[0], sdf_w[1], sdf_w[2], feat_w[0], feat_w[1], feat_w[2],
                                    rays_o.contiguous(), rays_d.contiguous(), t_starts.contiguous(),
-                                   t_ends.contiguous(), rays_per_view, rc)
+                                   t_ends.contiguous(), rays_per_view, rc, int(image_w))
     return dict(zip(names, outs))
