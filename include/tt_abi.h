@@ -19,6 +19,7 @@
  *                            VanillaMLP networks.py:67-104, get_shifted_sdf :131-154, analytic normal :329-335
  *                            -> aten grid_sampler_2d_backward via cuda_gridsample.py:55-58)
  *                           and forward_sdf :353-373 (flags without TT_Q_TEX / TT_Q_NORMAL).
+ *   tt_decode_rays          the geometry call of prop_sigma_fn (renderer :243-299 -> few_step...:273-306, sdf only)
  *   tt_render_fwd           GenerativeSpaceSDFVolumeRenderer._forward
  *                           generative_space_sdf_volume_renderer.py:326-431,467-472 (positions, geometry,
  *                           NoMaterial no_material.py:41-54, get_alpha neus_volume_renderer.py:93-117,
@@ -110,6 +111,12 @@ int tt_query_points(const float* packed, const tt_mlp_weights* w, const float* p
                     int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
                     float radius, float sdf_bias_radius, int32_t flags, float* out_sdf, float* out_sdf_grad,
                     float* out_features, void* stream);
+
+/* Decode only, along rays: sdf [+ sdf_grad if TT_Q_NORMAL] [+ features if TT_Q_TEX] at the mid-points of the
+ * intervals (n_rays,S).  The importance sampler's proposal pass (prop_sigma_fn, renderer :243-299) uses flags = 0. */
+int tt_decode_rays(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
+                   const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, int32_t flags, float* sdf,
+                   float* sdf_grad, float* features, void* stream);
 
 /* Forward render for explicit sample intervals.
  * rays_o, rays_d (n_rays,3); t_starts, t_ends (n_rays,S).

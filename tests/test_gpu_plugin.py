@@ -1,0 +1,142 @@
+"""GPU tests through the drop-in plugin API (registry names / Config / forward signature / output keys of the
+reference): eval + training renders, the importance sampler, PatchRenderer, geometry queries."""
+import pytest
+import torch
+
+import triplaneturbo_amd as tt
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda", 0)
+
+
+def _build(dev, seed=0, n_samples=16, n_imp=32):
+    torch.manual_seed(seed)
+    g = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
+    m = tt.find("no-material")({})
+    b = tt.find("solid-color-background")({})
+    cfg = dict(estimator="importance", trainable_variance=False, learned_variance_init=0.4605,
+               num_samples_per_ray=n_samples, num_samples_per_ray_importance=n_imp, near_plane=0.1, far_plane=4.0,
+               rgb_grad_shrink=[0, 1, 0.01, 20000])
+    r = tt.find("generative-space-sdf-volume-renderer")(cfg, geometry=g, material=m, background=b).to(dev)
+    return g, m, b, r, cfg
+
+
+def _weights(g):
+    sw, fw = g.mlp_weights()
+    return [w.detach().cpu() for w in sw], [w.detach().cpu() for w in fw]
+
+
+def test_eval_render_matches_oracle_and_keys(dev):
+    g, m, b, r, cfg = _build(dev)
+    r.eval()
+    gen = torch.Generator().manual_seed(1)
+    P, n_view, Hh, Ww = 1, 2, 6, 8
+    cache = torch.randn(P, 6, 32, 32, 32, generator=gen) * 0.5
+    ro, rd, c2w, cd = O.make_cameras(P * n_view, Hh, Ww)
+    ts, te = O.uniform_intervals(P * n_view * Hh * Ww, 24, 0.3, 3.2)
+    with torch.no_grad():
+        out = r(ro.to(dev), rd.to(dev), None, None, space_cache=cache.to(dev), text_embed=torch.zeros(P, 77, 1024),
+                camera_distances=cd.to(dev), c2w=c2w.to(dev), t_starts=ts.to(dev), t_ends=te.to(dev))
+    # eval-mode key set of the reference (renderer :442-449,460,477,503-504; no training extras)
+    assert set(out) == {"comp_rgb", "comp_rgb_fg", "comp_rgb_bg", "opacity", "depth", "z_variance", "disparity",
+                        "comp_normal", "comp_normal_cam_vis", "comp_normal_cam_vis_white"}
+    sw, fw = _weights(g)
+    want = O.render(cache.double(), [w.double() for w in sw], [w.double() for w in fw], ro.double(), rd.double(),
+                    ts.double(), te.double(), torch.ones(3).double(), cd.double(), c2w.double(), create_graph=False,
+                    training=False, inv_std=float(r.variance.inv_std))
+    w32 = O.render(cache, sw, fw, ro, rd, ts, te, torch.ones(3), cd, c2w, create_graph=False, training=False,
+                   inv_std=float(r.variance.inv_std))
+    for k in ("comp_rgb", "opacity", "depth", "z_variance", "disparity", "comp_normal_cam_vis"):
+        e_hip = (out[k].cpu().double() - want[k]).abs().max().item()
+        e_cpu = (w32[k].double() - want[k]).abs().max().item()
+        assert e_hip <= max(4 * e_cpu, 2e-5), (k, e_hip, e_cpu)
+
+
+def test_importance_sampler_matches_oracle_contract(dev):
+    g, m, b, r, cfg = _build(dev, n_samples=16, n_imp=32)
+    r.eval()  # stratified = False
+    gen = torch.Generator().manual_seed(2)
+    cache = torch.randn(1, 6, 32, 32, 32, generator=gen) * 0.5
+    ro, rd, c2w, cd = O.make_cameras(1, 5, 6)
+    ts, te = r.sample(cache.to(dev), ro.to(dev), rd.to(dev))
+    assert ts.shape == (30, 32 + 16 + 1)
+    sw, fw = _weights(g)
+
+    def sdf_fn(a, b2):  # oracle geometry at the interval mid-points
+        pos = ro.reshape(-1, 1, 3) + rd.reshape(-1, 1, 3) * ((a + b2) / 2)[..., None]
+        o = O.geometry_forward(pos.reshape(1, -1, 3), cache, sw, fw, output_normal=False)
+        return o["sdf"].reshape(a.shape)
+
+    wts, wte = O.importance_sampling(sdf_fn, 30, 32, 16, 0.1, 4.0, float(r.variance.inv_std), r.render_step_size)
+    # same contract, fp32 sdf differences of ~1e-6 move the resampled edges by <1e-4
+    assert (ts.cpu() - wts).abs().max().item() < 2e-4 and (te.cpu() - wte).abs().max().item() < 2e-4
+    assert (ts[:, 1:] >= ts[:, :-1]).all()
+
+
+def test_training_render_through_plugin_backward(dev):
+    g, m, b, r, cfg = _build(dev)
+    r.train()
+    r.update_step(0, 10000)  # rgb_grad_shrink = 0.505
+    gen = torch.Generator().manual_seed(3)
+    P, n_view, Hh, Ww = 2, 2, 4, 8
+    cache = (torch.randn(P, 6, 32, 32, 32, generator=gen) * 0.5).to(dev).requires_grad_(True)
+    ro, rd, c2w, cd = O.make_cameras(P * n_view, Hh, Ww)
+    out = r(ro.to(dev), rd.to(dev), None, torch.ones(3, device=dev), space_cache=cache,
+            text_embed=torch.zeros(P, 77, 1024), camera_distances=cd.to(dev), c2w=c2w.to(dev))
+    for k in ("weights", "t_points", "t_intervals", "t_dirs", "ray_indices", "points", "sdf", "sdf_orig", "features",
+              "normal", "shading_normal", "sdf_grad", "inv_std"):  # renderer :532-545
+        assert k in out, k
+    S = cfg["num_samples_per_ray"] + cfg["num_samples_per_ray_importance"] + 1
+    assert out["weights"].shape == (P * n_view * Hh * Ww * S, 1)
+    loss = out["comp_rgb"].mean() + (out["opacity"] ** 2 + 0.01).sqrt().mean() + \
+        ((out["sdf_grad"].norm(dim=-1) - 1) ** 2).mean()
+    loss.backward()
+    assert cache.grad is not None and torch.isfinite(cache.grad).all() and cache.grad.abs().sum() > 0
+    for w in g.parameters():
+        assert w.grad is not None and torch.isfinite(w.grad).all()
+
+
+def test_patch_renderer_training_and_eval(dev):
+    g, m, b, r, cfg = _build(dev)
+    p = tt.find("patch-renderer")({"patch_size": 8, "global_downsample": 3,
+                                   "base_renderer_type": "generative-space-sdf-volume-renderer",
+                                   "base_renderer": cfg}, geometry=g, material=m, background=b).to(dev)
+    gen = torch.Generator().manual_seed(4)
+    cache = (torch.randn(1, 6, 32, 32, 32, generator=gen) * 0.5).to(dev).requires_grad_(True)
+    ro, rd, c2w, cd = O.make_cameras(2, 24, 24)
+    kw = dict(space_cache=cache, text_embed=torch.zeros(1, 77, 1024), camera_distances=cd.to(dev), c2w=c2w.to(dev))
+    p.train()
+    torch.manual_seed(0)
+    out = p(ro.to(dev), rd.to(dev), None, torch.ones(3, device=dev), **kw)
+    assert out["comp_rgb"].shape == (2, 24, 24, 3) and out["opacity"].shape == (2, 24, 24, 1)
+    out["comp_rgb"].sum().backward()
+    assert torch.isfinite(cache.grad).all() and cache.grad.abs().sum() > 0
+    p.eval()
+    with torch.no_grad():
+        out = p(ro.to(dev), rd.to(dev), None, torch.ones(3, device=dev), **kw)
+    assert out["comp_rgb"].shape == (2, 24, 24, 3)
+
+
+def test_geometry_queries_match_oracle(dev):
+    g, *_ = _build(dev)
+    gen = torch.Generator().manual_seed(5)
+    cache = torch.randn(2, 6, 32, 16, 16, generator=gen) * 0.5
+    pts = torch.rand(4, 100, 3, generator=gen) * 2.4 - 1.2  # 2 views per prompt
+    sw, fw = _weights(g)
+    want = O.geometry_forward(pts, cache.repeat_interleave(2, 0), sw, fw, output_normal=True)
+    out = g(pts.to(dev), cache.to(dev), output_normal=True)
+    for k in ("sdf", "sdf_orig", "features", "sdf_grad", "normal"):
+        torch.testing.assert_close(out[k].cpu(), want[k], rtol=2e-4, atol=2e-5)
+    sdf = g.forward_sdf(pts.to(dev), cache.to(dev))
+    torch.testing.assert_close(sdf.cpu().reshape(-1, 1), want["sdf"], rtol=2e-4, atol=2e-5)
+    f, d = g.forward_field(pts.to(dev), cache.to(dev))
+    assert d is None and f.shape == (4, 100, 1)
+    ex = g.export(pts[:1].to(dev), cache[:1].to(dev))
+    torch.testing.assert_close(ex["features"].cpu().reshape(-1, 3), want["features"][:100], rtol=2e-4, atol=2e-5)

@@ -1,0 +1,170 @@
+"""CPU tests of the host side: plugin registry / configs / schedules, sampler contract, synthetic inputs,
+C-ABI surface (header <-> library <-> ctypes agreement).  No GPU, no compute calls into the library."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import triplaneturbo_amd as tt
+from oracle import cpu_ref as O
+from triplaneturbo_amd import _lib, parallel, registry, sampler, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_names_and_find():
+    for name in ("few-step-triplane-dual-stable-diffusion", "generative-space-sdf-volume-renderer", "patch-renderer",
+                 "no-material"):
+        assert isinstance(tt.find(name), type)
+    with pytest.raises(ValueError):
+        tt.register("patch-renderer")(object)  # names of extensions conflict (threestudio/__init__.py:8-11)
+    with pytest.raises(KeyError):
+        tt.find("does-not-exist")
+
+
+def test_config_fields_match_reference_names():
+    R = tt.find("generative-space-sdf-volume-renderer")
+    want = {"radius", "num_samples_per_ray", "randomized", "eval_chunk_size", "learned_variance_init",
+            "cos_anneal_end_steps", "use_volsdf", "near_plane", "far_plane", "trainable_variance", "estimator",
+            "grid_prune", "prune_alpha_threshold", "num_samples_per_ray_importance", "train_chunk_size",
+            "rgb_grad_shrink", "normal_direction", "weights"}  # renderer :40-71 + base classes
+    assert want == {f.name for f in R.Config.__dataclass_fields__.values()}
+    d = R.Config()
+    assert (d.num_samples_per_ray, d.learned_variance_init, d.estimator, d.near_plane) == (512, 0.3, "occgrid", 0.0)
+    G = tt.find("few-step-triplane-dual-stable-diffusion")
+    for f in ("n_feature_dims", "mlp_network_config", "normal_type", "sdf_bias", "sdf_bias_params", "rotate_planes",
+              "split_channels", "geo_interpolate", "tex_interpolate", "radius", "isosurface_deformable_grid"):
+        assert f in G.Config.__dataclass_fields__
+    with pytest.raises(KeyError):
+        registry.parse_structured(R.Config, {"not_a_field": 1})
+
+
+def _modules(renderer_cfg=None):
+    g = tt.find("few-step-triplane-dual-stable-diffusion")({})
+    m = tt.find("no-material")({})
+    b = tt.find("solid-color-background")({})
+    cfg = dict(estimator="importance", trainable_variance=False, learned_variance_init=0.4605, num_samples_per_ray=64,
+               num_samples_per_ray_importance=128, near_plane=0.1, far_plane=4.0, rgb_grad_shrink=[0, 1, 0.01, 20000])
+    cfg.update(renderer_cfg or {})
+    return g, m, b, cfg
+
+
+def test_renderer_construction_and_schedules():
+    g, m, b, cfg = _modules()
+    r = tt.find("generative-space-sdf-volume-renderer")(cfg, geometry=g, material=m, background=b)
+    assert abs(float(r.variance.inv_std) - 100.0) < 0.05  # exp(10 * 0.4605), yaml :137
+    assert abs(r.render_step_size - 1.732 * 2 / 64) < 1e-12
+    r.update_step(0, 0)
+    assert r.rgb_grad_shrink == 1
+    r.update_step(0, 10000)
+    assert abs(r.rgb_grad_shrink - 0.505) < 1e-9
+    r.update_step(0, 50000)
+    assert abs(r.rgb_grad_shrink - 0.01) < 1e-12
+    assert r.train().randomized is True and r.eval().randomized is False
+    assert list(g.state_dict().keys())[1:] == [f"{n}.layers.{i}.weight" for n in ("sdf_network", "feature_network")
+                                                for i in (0, 2, 4)]
+    for bad in ({"estimator": "occgrid"}, {"use_volsdf": True}, {"trainable_variance": True}):
+        _, _, _, c = _modules(bad)
+        with pytest.raises(NotImplementedError):
+            tt.find("generative-space-sdf-volume-renderer")(c, geometry=g, material=m, background=b)
+    p = tt.find("patch-renderer")({"patch_size": 40, "global_downsample": 3,
+                                   "base_renderer_type": "generative-space-sdf-volume-renderer",
+                                   "base_renderer": cfg}, geometry=g, material=m, background=b)
+    p.update_step(0, 10000)
+    assert abs(p.base_renderer.rgb_grad_shrink - 0.505) < 1e-9
+
+
+def test_C_schedule_matches_reference_semantics():
+    assert registry.C(0.3, 0, 5) == 0.3
+    assert registry.C([0, 1.0, 0.0, 20000], 0, 5000) == 0.75
+    assert registry.C([1.0, 0.0, 100], 0, 50) == 0.5  # 3-element form gets a 0 start step
+    assert registry.C([0, 0.0, 1.0, 10, 3.0, 20], 0, 15) == 2.0  # piecewise form
+    assert registry.C([0, 1.0, 0.0, 2.0], 1, 999) == 0.5  # float end_step => epochs
+
+
+def test_sampler_contract_equals_oracle():
+    g = torch.Generator().manual_seed(0)
+    n_rays = 37
+
+    def sdf_fn(ts, te):  # any deterministic smooth function of the mid-points
+        tm = (ts + te) / 2
+        return 0.4 * torch.cos(3.0 * tm) + 0.1 * (tm - 1.5)
+
+    a = sampler.importance_sampling(sdf_fn, n_rays, 128, 64, 0.1, 4.0, 100.0, 1.732 * 2 / 64)
+    b = O.importance_sampling(sdf_fn, n_rays, 128, 64, 0.1, 4.0, 100.0, 1.732 * 2 / 64)
+    assert a[0].shape == (n_rays, 193)  # 129 + 65 edges -> 193 intervals
+    torch.testing.assert_close(a[0], b[0], rtol=0, atol=0)
+    torch.testing.assert_close(a[1], b[1], rtol=0, atol=0)
+    assert (a[1] >= a[0]).all() and (a[0][:, 1:] == a[1][:, :-1]).all()
+    ts, te = sampler.uniform_intervals(5, 32, 0.1, 4.0, stratified=True, generator=g)
+    assert (te > ts).all() and ts[:, 0].eq(0.1).all() and torch.allclose(te[:, -1], torch.tensor(4.0))
+
+
+def test_synthetic_inputs_match_oracle_conventions():
+    a = synthetic.make_cameras(4, 6, 10, azimuth_start_deg=20.0)
+    b = O.make_cameras(4, 6, 10, azimuth_start_deg=20.0)
+    for x, y in zip(a, b):
+        torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a[1].norm(dim=-1), torch.ones(4, 6, 10))
+    assert abs(float(a[3][0]) - 0.9 / torch.tan(torch.tensor(torch.pi / 6)).item()) < 1e-6
+    ts, te = synthetic.uniform_intervals(3, 128, 0.1, 4.0)
+    to, _ = O.uniform_intervals(3, 128, 0.1, 4.0)
+    assert torch.equal(ts, to)
+
+
+def test_shard_prompts_partition():
+    for n, w in ((64, 8), (10, 4), (3, 8)):
+        parts = [list(parallel.shard_prompts(n, r, w)) for r in range(w)]
+        assert sum(parts, []) == list(range(n))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+# ---------------- C ABI surface ----------------
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "tt_abi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    path = _lib.build()  # hipcc cross-compiles for gfx950 without a GPU; no-op when up to date
+    lib = ctypes.CDLL(path)
+    syms = _header_symbols()
+    assert set(syms) == set(_lib.SYMBOLS), (syms, _lib.SYMBOLS)
+    for s in syms:
+        assert hasattr(lib, s), s
+    lib.tt_abi_version.restype = ctypes.c_int
+    lib.tt_strerror.restype = ctypes.c_char_p
+    assert lib.tt_abi_version() == 2
+    assert b"bad argument" in lib.tt_strerror(-1)
+
+
+def test_ctypes_struct_layout_matches_header(tmp_path):
+    code = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "tt_abi.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(tt_render_cfg), offsetof(tt_render_cfg, n_rays),
+         offsetof(tt_render_cfg, radius), offsetof(tt_render_cfg, flags), offsetof(tt_render_cfg, image_w),
+         sizeof(tt_mlp_weights), sizeof(tt_mlp_grads));
+  return 0; }'''
+    src = tmp_path / "t.c"
+    src.write_text(code)
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    c = _lib.RenderCfg
+    got = [ctypes.sizeof(c), c.n_rays.offset, c.radius.offset, c.flags.offset, c.image_w.offset,
+           ctypes.sizeof(_lib.MlpWeights), ctypes.sizeof(_lib.MlpWeights)]
+    assert [int(x) for x in out] == got
+
+
+def test_ops_refuse_cpu_tensors():
+    from triplaneturbo_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.planes_pack(torch.zeros(1, 6, 32, 8, 8))

@@ -458,3 +458,48 @@ extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const
     return tt_launch_march_fwd(rays_d, t_starts, t_ends, cfg, sdf, sdf_grad, features, opacity, depth, rgb_fg,
                                z_variance, normal_acc, weights, trans, s);
 }
+
+// Decode only (no march): sdf [+ sdf_grad] [+ features] at the mid-points of the given intervals.  Used by the
+// importance sampler's proposal pass (sdf head only: the reference evaluates and discards the texture path there,
+// few_step...:291,299-306) and by eval-style queries along rays.
+extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
+                              const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, int32_t flags,
+                              float* sdf, float* sdf_grad, float* features, void* stream) {
+    int st = tt_validate_cfg(cfg);
+    if (st != TT_OK) return st;
+    const bool need_n = (flags & TT_Q_NORMAL) != 0, need_t = (flags & TT_Q_TEX) != 0;
+    if (!packed || !w || !rays_o || !rays_d || !t_starts || !t_ends || !sdf || (need_n && !sdf_grad) ||
+        (need_t && !features))
+        return TT_ERR_BAD_ARG;
+    if (!w->w1 || !w->w2 || !w->w3 || (need_t && (!w->v1 || !w->v2 || !w->v3))) return TT_ERR_BAD_ARG;
+    int cus = tt_num_cus();
+    if (cus <= 0) return TT_ERR_DEVICE;
+    DecodeRaysParams p;
+    p.packed = packed;
+    p.w = to_ptrs(w);
+    p.rays_o = rays_o;
+    p.rays_d = rays_d;
+    p.t_starts = t_starts;
+    p.t_ends = t_ends;
+    p.cfg = *cfg;
+    p.sdf = sdf;
+    p.sdf_grad = sdf_grad;
+    p.features = features;
+    const long long slots = 2LL * cus * 4;
+    p.n_items = tt_make_geom(cfg, slots, &p.geom);
+    long long blocks = 2LL * cus;
+    long long need = (p.n_items + 3) / 4;
+    if (blocks > need) blocks = need;
+    blocks = (blocks + 7) / 8 * 8;
+    dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (need_n && need_t)
+        hipLaunchKernelGGL((k_decode_rays<true, true>), grid, blk, 0, s, p);
+    else if (need_n)
+        hipLaunchKernelGGL((k_decode_rays<true, false>), grid, blk, 0, s, p);
+    else if (need_t)
+        hipLaunchKernelGGL((k_decode_rays<false, true>), grid, blk, 0, s, p);
+    else
+        hipLaunchKernelGGL((k_decode_rays<false, false>), grid, blk, 0, s, p);
+    return tt_check_launch();
+}

@@ -1,0 +1,151 @@
+"""Decode half of the reference geometry plugin `few-step-triplane-dual-stable-diffusion`
+(custom/triplaneturbo/models/geometry/few_step_triplane_dual_stable_diffusion.py:20-447): the two bias-free MLPs,
+plane sampling and the per-point queries.  The SD-UNet/VAE triplane *generator* half stays stock PyTorch-ROCm and is
+injected as `space_generator` (any object with forward / forward_denoise / forward_decode); it is out of scope.
+
+Same registry name, Config fields, method names, argument meaning and state-dict keys
+(`sdf_network.layers.{0,2,4}.weight`, `feature_network.layers.{0,2,4}.weight`) as the reference.
+Per-point queries run on the HIP kernels (tt_query_points); the differentiable training path of the volume renderer
+does not go through `forward` at all (it is fused in tt_render_fwd / tt_render_bwd_*)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import BaseModule, register
+
+Tensor = torch.Tensor
+
+
+class VanillaMLP(nn.Module):
+    """threestudio/models/networks.py:67-104: Linear(bias=False) + ReLU, no output activation."""
+
+    def __init__(self, dim_in: int, dim_out: int, config: dict):
+        super().__init__()
+        n_neurons, n_hidden = config["n_neurons"], config["n_hidden_layers"]
+        if config.get("otype", "VanillaMLP") != "VanillaMLP" or config.get("output_activation", "none") not in (
+                None, "none"):
+            raise NotImplementedError("only otype=VanillaMLP, output_activation=none (the reference config)")
+        layers = [nn.Linear(dim_in, n_neurons, bias=False), nn.ReLU(inplace=True)]
+        for _ in range(n_hidden - 1):
+            layers += [nn.Linear(n_neurons, n_neurons, bias=False), nn.ReLU(inplace=True)]
+        layers += [nn.Linear(n_neurons, dim_out, bias=False)]
+        self.layers = nn.Sequential(*layers)
+
+    def weights(self):
+        return [m.weight for m in self.layers if isinstance(m, nn.Linear)]
+
+
+@register("few-step-triplane-dual-stable-diffusion")
+class StableDiffusionTriplaneDualAttention(BaseModule):
+    @dataclass
+    class Config(BaseModule.Config):
+        radius: float = 1.0
+        n_feature_dims: int = 3
+        space_generator_config: dict = field(default_factory=dict)
+        mlp_network_config: dict = field(default_factory=lambda: {
+            "otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64,
+            "n_hidden_layers": 2})
+        backbone: str = "few_step_triplane_dual_stable_diffusion"
+        normal_type: Optional[str] = "analytic"
+        finite_difference_normal_eps: Union[float, str] = 0.01
+        sdf_bias: Union[float, str] = "sphere"
+        sdf_bias_params: Optional[Any] = 0.5
+        isosurface_remove_outliers: bool = False
+        isosurface_deformable_grid: bool = False
+        rotate_planes: Optional[str] = "v1"
+        split_channels: Optional[str] = "v1"
+        geo_interpolate: str = "v1"
+        tex_interpolate: str = "v2"
+
+    cfg: Config
+
+    def configure(self, space_generator: Optional[nn.Module] = None) -> None:
+        c = self.cfg
+        if c.rotate_planes != "v1" or c.geo_interpolate != "v1" or c.tex_interpolate != "v2" or \
+                c.normal_type != "analytic" or c.sdf_bias != "sphere" or c.n_feature_dims != 3:
+            raise NotImplementedError(
+                "the HIP hot path implements the reference training config: rotate_planes=v1, geo_interpolate=v1, "
+                "tex_interpolate=v2, normal_type=analytic, sdf_bias=sphere, n_feature_dims=3 "
+                "(configs/TriplaneTurbo_v1.yaml:74-85)")
+        if c.mlp_network_config["n_neurons"] != 64 or c.mlp_network_config["n_hidden_layers"] != 2:
+            raise NotImplementedError("kernels are built for 64 neurons x 2 hidden layers")
+        self.space_generator = space_generator
+        self.sdf_network = VanillaMLP(32, 1, c.mlp_network_config)
+        self.feature_network = VanillaMLP(96, c.n_feature_dims, c.mlp_network_config)
+        if c.isosurface_deformable_grid:
+            self.deformation_network = VanillaMLP(32, 3, c.mlp_network_config)
+        self.register_buffer("bbox", torch.as_tensor([[-c.radius] * 3, [c.radius] * 3], dtype=torch.float32))
+
+    # ---- generator half: delegated (stock PyTorch-ROCm) ----
+    def _gen(self):
+        if self.space_generator is None:
+            raise RuntimeError("no space_generator attached: the SD-UNet/VAE triplane generator is out of scope of "
+                               "triplaneturbo_amd; pass one to the constructor or supply space_cache directly")
+        return self.space_generator
+
+    def generate_space_cache(self, styles, text_embed):
+        return self._gen()(text_embed=text_embed, styles=styles)
+
+    def denoise(self, noisy_input, text_embed, timestep):
+        return self._gen().forward_denoise(text_embed=text_embed, noisy_input=noisy_input, t=timestep)
+
+    def decode(self, latents):
+        return self._gen().forward_decode(latents=latents)  # split_channels v1 is the generator's job here
+
+    # ---- decode half ----
+    def mlp_weights(self) -> Tuple[list, list]:
+        return self.sdf_network.weights(), self.feature_network.weights()
+
+    @torch.no_grad()
+    def forward(self, points: Tensor, space_cache: Tensor, output_normal: bool = False) -> Dict[str, Tensor]:
+        """few_step...:273-351.  points (B,N,3); space_cache (P,6,32,H,W) with B a multiple of P (view b reads
+        prompt b // (B/P)).  Inference-style query (no autograd graph)."""
+        B, N, _ = points.shape
+        P = space_cache.shape[0]
+        packed = ops.planes_pack(space_cache.detach())
+        sw, fw = self.mlp_weights()
+        sdf, grad, feat = ops.query_points(packed, [w.detach() for w in sw], [w.detach() for w in fw],
+                                           points.detach().float(), views_per_prompt=B // P,
+                                           radius=self.cfg.radius, sdf_bias_radius=float(self.cfg.sdf_bias_params),
+                                           need_normal=output_normal, need_features=True)
+        bias = (points.reshape(-1, 3) ** 2).sum(-1, keepdim=True).sqrt() - float(self.cfg.sdf_bias_params)
+        out = {"sdf": sdf, "sdf_orig": sdf - bias, "features": feat}
+        if output_normal:
+            normal = torch.nn.functional.normalize(grad, dim=-1)
+            out.update(normal=normal, shading_normal=normal, sdf_grad=grad)
+        return out
+
+    @torch.no_grad()
+    def forward_sdf(self, points: Tensor, space_cache: Tensor) -> Tensor:
+        """few_step...:353-373"""
+        B = points.shape[0]
+        pts = points.reshape(B, -1, 3)
+        packed = ops.planes_pack(space_cache.detach())
+        sw, _ = self.mlp_weights()
+        sdf, _, _ = ops.query_points(packed, [w.detach() for w in sw], None, pts.float(),
+                                     views_per_prompt=B // space_cache.shape[0], radius=self.cfg.radius,
+                                     sdf_bias_radius=float(self.cfg.sdf_bias_params), need_normal=False,
+                                     need_features=False)
+        return sdf.reshape(*points.shape[:-1], 1)
+
+    @torch.no_grad()
+    def forward_field(self, points: Tensor, space_cache: Tensor):
+        """few_step...:375-394.  The deformation head is a SURVEY 8(f) 'next' row and is not built yet."""
+        if self.cfg.isosurface_deformable_grid:
+            raise NotImplementedError("deformation_network query (SURVEY.md 8f rank 1) is not implemented yet")
+        return self.forward_sdf(points, space_cache), None
+
+    def forward_level(self, field: Tensor, threshold: float) -> Tensor:
+        return field - threshold
+
+    @torch.no_grad()
+    def export(self, points: Tensor, space_cache: Tensor, **kwargs) -> Dict[str, Any]:
+        """few_step...:402-430 (vertex colouring: feature net only)."""
+        orig = points.shape
+        out = self.forward(points.reshape(1, -1, 3), space_cache, output_normal=False)
+        return {"features": out["features"].reshape(*orig[:-1], self.cfg.n_feature_dims)}

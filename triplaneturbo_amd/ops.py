@@ -259,3 +259,28 @@ def render_samples(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequenc
                                    rays_o.contiguous(), rays_d.contiguous(), t_starts.contiguous(),
                                    t_ends.contiguous(), rays_per_view, rc, int(image_w))
     return dict(zip(names, outs))
+
+
+@torch.no_grad()
+def decode_rays(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Sequence[Tensor]], rays_o: Tensor,
+                rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, rays_per_view: int, rc: RenderConfig,
+                need_normal: bool = False, need_features: bool = False, image_w: int = 0):
+    """Per-sample decode along rays without the march (no grad): sdf (n_rays,S), optionally sdf_grad (n_rays,S,3)
+    and features (n_rays,S,3).  The sampler's proposal pass uses the sdf-only form."""
+    packed = _chk(packed, "packed")
+    rays_o, rays_d = _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d")
+    t_starts, t_ends = _chk(t_starts, "t_starts"), _chk(t_ends, "t_ends")
+    n_rays, S = t_starts.shape
+    cfg = _make_cfg(packed, n_rays, rays_per_view, S, rc, False, image_w)
+    wst, keep = _weights_struct(sdf_w, feat_w if need_features else None)
+    f32 = dict(device=packed.device, dtype=torch.float32)
+    sdf = torch.empty((n_rays, S), **f32)
+    grad = torch.empty((n_rays, S, 3), **f32) if need_normal else None
+    feat = torch.empty((n_rays, S, 3), **f32) if need_features else None
+    flags = (_lib.TT_Q_NORMAL if need_normal else 0) | (_lib.TT_Q_TEX if need_features else 0)
+    with _timed("tt_decode_rays"):
+        st = _lib.load().tt_decode_rays(_ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts),
+                                        _ptr(t_ends), ctypes.byref(cfg), flags, _ptr(sdf), _ptr(grad), _ptr(feat),
+                                        _stream())
+    _lib.check(st, "tt_decode_rays")
+    return sdf, grad, feat

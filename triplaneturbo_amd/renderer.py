@@ -1,0 +1,255 @@
+"""`generative-space-sdf-volume-renderer` and `patch-renderer`: same registry names, Config fields, forward
+signature, output-dict keys, update_step / train / eval behaviour as the reference
+(custom/triplaneturbo/models/renderers/generative_space_sdf_volume_renderer.py:38-565,
+threestudio/models/renderers/neus_volume_renderer.py:38-117, threestudio/models/renderers/patch_renderer.py).
+All per-sample work runs in the HIP kernels; this file is orchestration."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional, ops, sampler
+from .registry import BaseModule, C, find, register
+
+Tensor = torch.Tensor
+
+
+class LearnedVariance(nn.Module):
+    """renderer :24-35"""
+
+    def __init__(self, init_val, requires_grad=True):
+        super().__init__()
+        self.register_parameter("_inv_std", nn.Parameter(torch.tensor(float(init_val)), requires_grad=requires_grad))
+
+    @property
+    def inv_std(self):
+        return torch.exp(self._inv_std * 10.0)
+
+    def forward(self, x):
+        return torch.ones_like(x) * self.inv_std.clamp(1.0e-6, 1.0e6)
+
+
+@register("no-material")
+class NoMaterial(BaseModule):
+    """threestudio/models/materials/no_material.py: colour = activation(features).  The activation is fused into the
+    HIP kernels, which implement the reference config's `sigmoid-mipnerf` only."""
+
+    @dataclass
+    class Config(BaseModule.Config):
+        n_output_dims: int = 3
+        color_activation: str = "sigmoid-mipnerf"
+        input_feature_dims: Optional[int] = None
+        mlp_network_config: Optional[dict] = None
+        requires_normal: bool = False
+
+    cfg: Config
+
+    def configure(self) -> None:
+        if self.cfg.color_activation != "sigmoid-mipnerf" or self.cfg.mlp_network_config is not None:
+            raise NotImplementedError("fused material: color_activation=sigmoid-mipnerf without a material MLP "
+                                      "(configs/TriplaneTurbo_v1.yaml:103-107)")
+        self.requires_normal = self.cfg.requires_normal
+
+    def forward(self, features: Tensor, **kwargs) -> Tensor:
+        return torch.sigmoid(features) * (1 + 2 * 0.001) - 0.001
+
+
+@register("solid-color-background")
+class SolidColorBackground(BaseModule):
+    """Minimal background (the reference's hashgrid+hypernet background is a SURVEY 8(f) 'next' row): a constant
+    colour per ray, which is also what the reference uses at eval time (`eval_color`, yaml :114)."""
+
+    @dataclass
+    class Config(BaseModule.Config):
+        color: tuple = (1.0, 1.0, 1.0)
+
+    cfg: Config
+
+    def forward(self, dirs: Tensor, **kwargs) -> Tensor:
+        col = torch.as_tensor(self.cfg.color, device=dirs.device, dtype=dirs.dtype)
+        return col.expand(*dirs.shape[:-1], 3)
+
+
+@register("generative-space-sdf-volume-renderer")
+class GenerativeSpaceSDFVolumeRenderer(BaseModule):
+    @dataclass
+    class Config(BaseModule.Config):
+        radius: float = 1.0
+        num_samples_per_ray: int = 512
+        randomized: bool = True
+        eval_chunk_size: int = 320000  # accepted, unused: the fused kernels never materialise per-layer activations
+        learned_variance_init: float = 0.3
+        cos_anneal_end_steps: int = 0
+        use_volsdf: bool = False
+        near_plane: float = 0.0
+        far_plane: float = 1e10
+        trainable_variance: bool = True
+        estimator: str = "occgrid"
+        grid_prune: bool = True
+        prune_alpha_threshold: bool = True
+        num_samples_per_ray_importance: int = 64
+        train_chunk_size: int = 0  # accepted, unused (see eval_chunk_size)
+        rgb_grad_shrink: Any = 1.0
+        normal_direction: str = "camera"
+
+    cfg: Config
+
+    def configure(self, geometry, material, background) -> None:
+        c = self.cfg
+        if c.estimator != "importance":
+            raise NotImplementedError("estimator must be 'importance' (the reference raises for 'occgrid', :83-85)")
+        if c.use_volsdf:
+            raise NotImplementedError("use_volsdf=True is not part of the accelerated path (yaml :135)")
+        if c.trainable_variance:
+            raise NotImplementedError("trainable_variance=False only (yaml :136 'important!'): the kernels take "
+                                      "inv_std as a constant")
+        assert c.normal_direction in ["front", "camera", "world"]
+        self.geometry, self.material, self.background = geometry, material, background
+        if material is not None and not isinstance(material, NoMaterial):
+            raise NotImplementedError("the fused path implements NoMaterial (sigmoid-mipnerf) only")
+        self.variance = LearnedVariance(c.learned_variance_init, requires_grad=False)
+        self.render_step_size = 1.732 * 2 * c.radius / c.num_samples_per_ray  # neus_volume_renderer.py:84-86
+        self.cos_anneal_ratio = 1.0
+        self.randomized = c.randomized
+        self.rgb_grad_shrink = C(c.rgb_grad_shrink, 0, 0)
+        self.register_buffer("bbox", torch.as_tensor([[-c.radius] * 3, [c.radius] * 3], dtype=torch.float32))
+
+    # ------------------------------------------------------------------------------------------
+    def _render_config(self) -> ops.RenderConfig:
+        g = self.geometry.cfg
+        return ops.RenderConfig(radius=self.cfg.radius, sdf_bias_radius=float(g.sdf_bias_params),
+                                inv_std=float(self.variance.inv_std), cos_anneal_ratio=float(self.cos_anneal_ratio),
+                                rgb_grad_shrink=float(self.rgb_grad_shrink))
+
+    def sample(self, space_cache: Tensor, rays_o: Tensor, rays_d: Tensor, generator=None):
+        """ImportanceEstimator.sampling + prop_sigma_fn (estimators.py:22-101, renderer :243-316), no grad."""
+        B, Hh, Ww, _ = rays_o.shape
+        n_rays = B * Hh * Ww
+        rc = self._render_config()
+        sw, _ = self.geometry.mlp_weights()
+        packed = ops.planes_pack(space_cache.detach())
+        ro, rd = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
+
+        def sdf_fn(ts, te):
+            sdf, _, _ = ops.decode_rays(packed, [w.detach() for w in sw], None, ro, rd, ts, te, Hh * Ww, rc,
+                                        image_w=Ww)
+            return sdf
+
+        return sampler.importance_sampling(
+            sdf_fn, n_rays, self.cfg.num_samples_per_ray_importance, self.cfg.num_samples_per_ray,
+            self.cfg.near_plane, self.cfg.far_plane, rc.inv_std, self.render_step_size, device=rays_o.device,
+            stratified=self.randomized, generator=generator)
+
+    def forward(self, rays_o: Tensor, rays_d: Tensor, light_positions: Optional[Tensor] = None,
+                bg_color: Optional[Tensor] = None, noise: Optional[Tensor] = None,
+                space_cache: Optional[Tensor] = None, text_embed: Optional[Tensor] = None,
+                camera_distances: Optional[Tensor] = None, c2w: Optional[Tensor] = None, t_starts=None, t_ends=None,
+                **kwargs) -> Dict[str, Tensor]:
+        """renderer :98-213.  rays (B,H,W,3); space_cache (P,6,32,R,R), B = P * n_view (view b uses prompt
+        b // n_view -- the reference's repeat_interleave :120-143 is replaced by an index in the kernels, and its
+        per-view eval loop :158-185 by the same single call).  Extra kwargs t_starts/t_ends (n_rays,S) bypass the
+        sampler (used by the parity tests and the benchmark)."""
+        B, Hh, Ww, _ = rays_o.shape
+        if space_cache is None:
+            space_cache = self.geometry.generate_space_cache(styles=noise, text_embed=text_embed)
+        if not torch.is_tensor(space_cache):
+            raise NotImplementedError("dict space caches (hyper-net variants, renderer :128-141) are out of scope")
+        P = space_cache.shape[0]
+        if text_embed is not None:
+            assert text_embed.shape[0] == P
+        assert B % P == 0, "batch of views must be a multiple of the number of prompts"
+        if t_starts is None:
+            t_starts, t_ends = self.sample(space_cache, rays_o, rays_d)
+        if bg_color is None:
+            text_bg = kwargs.get("text_embed_bg", text_embed)
+            comp_rgb_bg = self.background(dirs=rays_d, text_embed=text_bg) if getattr(
+                self.background, "enabling_hypernet", False) else self.background(dirs=rays_d)
+            bg_color = comp_rgb_bg
+        else:
+            comp_rgb_bg = None
+        sw, fw = self.geometry.mlp_weights()
+        rc = self._render_config()
+        grad_on = self.training and torch.is_grad_enabled()
+        ctx = torch.enable_grad() if grad_on else torch.no_grad()
+        with ctx:
+            out = functional.volume_render(space_cache, sw, fw, rays_o, rays_d, t_starts, t_ends, bg_color,
+                                           camera_distances, c2w, rc, training=self.training,
+                                           normal_direction=self.cfg.normal_direction, comp_rgb_bg=comp_rgb_bg)
+        if self.training:
+            out["inv_std"] = self.variance.inv_std
+        return out
+
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False) -> None:
+        self.rgb_grad_shrink = C(self.cfg.rgb_grad_shrink, epoch, global_step)  # renderer :548-553
+        self.cos_anneal_ratio = 1.0 if self.cfg.cos_anneal_end_steps == 0 else min(
+            1.0, global_step / self.cfg.cos_anneal_end_steps)  # neus_volume_renderer.py:385-389
+
+    def train(self, mode=True):
+        self.randomized = mode and self.cfg.randomized
+        if hasattr(self.geometry, "train"):
+            self.geometry.train(mode)
+        return super().train(mode=mode)
+
+    def eval(self):
+        self.randomized = False
+        if hasattr(self.geometry, "eval"):
+            self.geometry.eval()
+        return super().eval()
+
+
+@register("patch-renderer")
+class PatchRenderer(BaseModule):
+    """threestudio/models/renderers/patch_renderer.py: training = low-res global render + random hi-res patch."""
+
+    @dataclass
+    class Config(BaseModule.Config):
+        radius: float = 1.0
+        patch_size: int = 128
+        base_renderer_type: str = ""
+        base_renderer: Optional[dict] = None
+        global_detach: bool = False
+        global_downsample: int = 4
+
+    cfg: Config
+
+    def configure(self, geometry, material, background) -> None:
+        self.base_renderer = find(self.cfg.base_renderer_type)(self.cfg.base_renderer, geometry=geometry,
+                                                               material=material, background=background)
+
+    def forward(self, rays_o: Tensor, rays_d: Tensor, light_positions: Optional[Tensor] = None,
+                bg_color: Optional[Tensor] = None, **kwargs) -> Dict[str, Tensor]:
+        B, H, W, _ = rays_o.shape
+        if not self.base_renderer.training:
+            return self.base_renderer(rays_o, rays_d, light_positions, bg_color, **kwargs)
+        ds = self.cfg.global_downsample
+        g_o = F.interpolate(rays_o.permute(0, 3, 1, 2), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
+        g_d = F.interpolate(rays_d.permute(0, 3, 1, 2), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
+        out_global = self.base_renderer(g_o.contiguous(), g_d.contiguous(), light_positions, bg_color, **kwargs)
+        PS = self.cfg.patch_size
+        px = torch.randint(0, W - PS, (1,)).item()
+        py = torch.randint(0, H - PS, (1,)).item()
+        out = self.base_renderer(rays_o[:, py:py + PS, px:px + PS].contiguous(),
+                                 rays_d[:, py:py + PS, px:px + PS].contiguous(), light_positions, bg_color, **kwargs)
+        valid = [k for k in out if torch.is_tensor(out[k]) and out[k].ndim == out["comp_rgb"].ndim
+                 and out[k][..., 0].shape == out["comp_rgb"][..., 0].shape]
+        for k in valid:
+            up = F.interpolate(out_global[k].permute(0, 3, 1, 2), (H, W), mode="bilinear").permute(0, 2, 3, 1)
+            if self.cfg.global_detach:
+                up = up.detach()
+            up = up.clone()
+            up[:, py:py + PS, px:px + PS] = out[k]
+            out_global[k] = up
+        return out_global
+
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False) -> None:
+        self.base_renderer.update_step(epoch, global_step, on_load_weights)
+
+    def train(self, mode=True):
+        return self.base_renderer.train(mode)
+
+    def eval(self):
+        return self.base_renderer.eval()
