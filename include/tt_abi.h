@@ -151,6 +151,16 @@ int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, const float*
                       const float* features, const float* g_rgb_fg, const float* g_features, float* grad_packed,
                       const tt_mlp_grads* grads, void* stream);
 
+/* Operator-level drop-in for the reference's pybind op `gridsample_grad2.grad2_2d`
+ * (gridsample_cuda.cpp:26-37): backward of aten::grid_sampler_2d_backward, bilinear.  Contiguous fp32:
+ * input / grad2_grad_input / grad_input (n,c,h,w); grid / grad2_grad_grid / grad_grid (n,Ho,Wo,2);
+ * grad_output / grad_grad_output (n,c,Ho,Wo); n_points_per_batch = Ho*Wo.  padding_mode 0 = zeros and
+ * align_corners = 0 only (TT_ERR_UNSUPPORTED otherwise).  grad_input is zero-filled inside (like the reference). */
+int tt_grid_sample_2d_grad2(const float* grad2_grad_input, const float* grad2_grad_grid, const float* grad_output,
+                            const float* input, const float* grid, int32_t n, int32_t c, int32_t h, int32_t w,
+                            int64_t n_points_per_batch, int32_t padding_mode, int32_t align_corners,
+                            float* grad_grad_output, float* grad_input, float* grad_grid, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

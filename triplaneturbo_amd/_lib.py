@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomic
 # every symbol include/tt_abi.h declares (tests check the header and this list agree)
 SYMBOLS = [
     "tt_strerror", "tt_abi_version", "tt_planes_pack", "tt_planes_unpack_grad", "tt_query_points",
-    "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex",
+    "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2",
 ]
 
 
@@ -107,7 +107,7 @@ def load() -> ctypes.CDLL:
     optional = {
         "tt_render_bwd_geo": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 14 + [_P, _P, _wp, _P],
         "tt_render_bwd_tex": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 4 + [_P, _wp, _P],
-        "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 5 + [_P] * 3 + [_P],
+        "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
     }
     for name, argtypes in optional.items():
         if name in SYMBOLS:
