@@ -123,26 +123,30 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
         }
     }
     lost |= __shfl_xor(lost, 32);
-    // ---- G = M Q on the matrix cores, flushed tile by tile ----
+    // ---- G = M Q on the matrix cores: the two 32-slot tiles advance as independent accumulator chains ----
+    f32x4 a4[2][4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        f32x4 a4[4];
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4)
-            a4[t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
-        f32x16 acc = ZERO16;
+            a4[m][t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
+    f32x16 acc0 = ZERO16, acc1 = ZERO16;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float b = Qs[(t + 16 * hi) * 33 + i];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t >> 2][t & 3], b, acc, 0, 0, 0);
-        }
+    for (int t = 0; t < 16; ++t) {
+        const float b = Qs[(t + 16 * hi) * 33 + i];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0][t >> 2][t & 3], b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1][t >> 2][t & 3], b, acc1, 0, 0, 0);
+    }
+    // flush: one 128-byte atomic per occupied slot, straight from the accumulators (slot of reg 4g+e = LIDX)
+    if (!no_global) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const i32x4 key4 = *reinterpret_cast<const i32x4*>(tags + 32 * m + 8 * g + 4 * hi);  // slots LIDX(4g.., hi)
+            const i32x4 k0 = *reinterpret_cast<const i32x4*>(tags + 8 * g + 4 * hi);
+            const i32x4 k1 = *reinterpret_cast<const i32x4*>(tags + 32 + 8 * g + 4 * hi);
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) {
-                const float v = acc[4 * g + e2];
-                if (key4[e2] != -1 && v != 0.f && !no_global) atomicAdd(grad + (size_t)key4[e2] * TT_C + i, v);
+                if (k0[e2] != -1) atomicAdd(grad + (size_t)k0[e2] * TT_C + i, acc0[4 * g + e2]);
+                if (k1[e2] != -1) atomicAdd(grad + (size_t)k1[e2] * TT_C + i, acc1[4 * g + e2]);
             }
         }
     }
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     tags[lane] = -1;
     __syncthreads();
     const int S = cfg.n_samples;
-    const ItemRange ir = item_range(p.n_items);
+    const ItemRange ir = item_range(tg.n_blocks, tg.n_chunks);
     const int H = cfg.plane_h, W = cfg.plane_w;
     const size_t HW = (size_t)H * W;
     const size_t plane_stride = 6 * HW * TT_C;
@@ -220,8 +224,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
 
 #pragma nounroll
     for (long long item = ir.lo; item < ir.hi; item += ir.stride) {
-        const long long b = item / tg.n_chunks;
-        const int ck = (int)(item - b * tg.n_chunks);
+        long long b;
+        int ck;
+        item_decode(ir, item, tg.order, tg.n_chunks, b, ck);
         bool rvalid;
         const long long ray = tile_ray(tg, b, i, rvalid);
         const int view = (int)(ray / cfg.rays_per_view);
@@ -244,8 +249,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius),
                         Z = scale_coord(pz, cfg.radius);
             // ---- recompute the geometry decode ----
-            float f[16], jx[16], jy[16], jz[16];
-            const bool any = __any(gather_geo<true>(pbase, H, W, X, Y, Z, rvalid, ju, jv, hi, f, jx, jy, jz, cfg.flags));
+            float f[16], u[16];  // u = sbar f + J gbar
+            const bool any =
+                __any(gather_geo_bwd(pbase, H, W, X, Y, Z, rvalid, sbar, gbx, gby, gbz, ju, jv, hi, f, u, cfg.flags));
             if (!any) continue;  // exact: no in-bounds texel => f = J = 0, every mask false
             float h1[32], h2[32], a2[32], a1[32], q[16];
             mv_fwd<64, 32>(L + OFF_W1, f, h1, i, hi);
@@ -266,12 +272,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             mv_bwd<32, 64>(L + OFF_W1, a1, q, i, hi);
             // ---- network + plane gradients ----
             {
-                float u[16], qb[16];
+                float qb[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    qb[r] = fmaf(jx[r], gbx, fmaf(jy[r], gby, jz[r] * gbz));  // qbar = J gbar
-                    u[r] = fmaf(sbar, f[r], qb[r]);
-                }
+                for (int r = 0; r < 16; ++r) qb[r] = fmaf(-sbar, f[r], u[r]);  // qbar = J gbar = u - sbar f
                 const bool do_wgrad = !(cfg.flags & TT_DBG_NO_WGRAD);
                 // dW1 += a1 (sbar f + qbar)^T
                 if (do_wgrad) {
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     const int H = cfg.plane_h, W = cfg.plane_w;
     const size_t HW = (size_t)H * W;
     const size_t plane_stride = 6 * HW * TT_C;
-    const ItemRange ir = item_range(p.n_items);
+    const ItemRange ir = item_range(tg.n_blocks, tg.n_chunks);
     const float shrink = cfg.rgb_grad_shrink;
 
     f32x16 accV1a[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};  // dV1[:, 0:64]
@@ -388,8 +391,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
 
 #pragma nounroll
     for (long long item = ir.lo; item < ir.hi; item += ir.stride) {
-      const long long b = item / tg.n_chunks;
-      const int ck = (int)(item - b * tg.n_chunks);
+      long long b;
+      int ck;
+      item_decode(ir, item, tg.order, tg.n_chunks, b, ck);
       bool rvalid;
       const long long ray = tile_ray(tg, b, i, rvalid);
       const bool valid = rvalid;
@@ -591,7 +595,7 @@ extern "C" int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, c
     p.ws = workspace;
     p.grad_packed = grad_packed;
     p.grads = to_gptrs(grads);
-    p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom);
+    p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom, 1);
     long long blocks = persistent_blocks(p.n_items, cus);
     hipLaunchKernelGGL(k_decode_bwd_geo, dim3((unsigned)blocks), dim3(256), 0, s, p);
     return tt_check_launch();
@@ -625,7 +629,7 @@ extern "C" int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, c
     p.g_features = g_features;
     p.grad_packed = grad_packed;
     p.grads = to_gptrs(grads);
-    p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom);
+    p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom, 1);
     long long blocks = persistent_blocks(p.n_items, cus);
     hipLaunchKernelGGL(k_decode_bwd_tex, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return tt_check_launch();

@@ -82,42 +82,78 @@ __device__ __forceinline__ void lds_load_tex_weights(float* L, const MlpPtrs& w)
 
 // ---- MFMA mat-vec products on a 32-sample tile -----------------------------------------------------
 // y[NOUT] = W[NOUT][NIN] * x[NIN]   (W in LDS, row stride NIN+4).  x, y in the LIDX register layout.
+// All NOUT/32 row tiles advance together: their accumulator chains are independent, so one wave keeps the
+// matrix pipe busy (a single dependent chain stalls on the 64-cycle result latency plus the LDS wait), and the
+// A operands of k-group g+1 are fetched while group g multiplies.
 template <int NOUT, int NIN>
 __device__ __forceinline__ void mv_fwd(const float* Wl, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i,
                                        int hi) {
+    constexpr int MT = NOUT / 32;
+    f32x16 acc[MT];
+    f32x4 a_cur[MT], a_nxt[MT];
+    const float* row = Wl + i * (NIN + 4) + 4 * hi;
 #pragma unroll
-    for (int m = 0; m < NOUT / 32; ++m) {
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* row = Wl + (32 * m + i) * (NIN + 4) + 4 * hi;
+    for (int m = 0; m < MT; ++m) {
+        acc[m] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        a_cur[m] = *reinterpret_cast<const f32x4*>(row + 32 * m * (NIN + 4));
+    }
 #pragma unroll
-        for (int g = 0; g < NIN / 8; ++g) {
-            f32x4 a = *reinterpret_cast<const f32x4*>(row + 8 * g);  // columns LIDX(4g..4g+3, hi)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x[4 * g + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], x[4 * g + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], x[4 * g + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], x[4 * g + 3], acc, 0, 0, 0);
+    for (int g = 0; g < NIN / 8; ++g) {
+        if (g + 1 < NIN / 8) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                a_nxt[m] = *reinterpret_cast<const f32x4*>(row + 32 * m * (NIN + 4) + 8 * (g + 1));
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[k];
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][k], x[4 * g + k], acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
     }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k];
 }
 
-// y[NOUT] = W[NIN][NOUT]^T * x[NIN]   (W in LDS as stored, row stride NOUT+4).
+// y[NOUT] = W[NIN][NOUT]^T * x[NIN]   (W in LDS as stored, row stride STRIDE = NOUT+4).
 // STRIDE != NOUT+4 selects a 32m-column slice of a wider stored matrix (Wl already offset to its first column).
+// With a single row tile (NOUT = 32) the k range is split into two independent accumulator chains.
 template <int NOUT, int NIN, int STRIDE = NOUT + 4>
 __device__ __forceinline__ void mv_bwd(const float* Wl, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i,
                                        int hi) {
+    constexpr int MT = NOUT / 32;
     const float* base = Wl + 4 * hi * STRIDE + i;
+    if (MT == 1) {
+        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc1 = acc0;
 #pragma unroll
-    for (int m = 0; m < NOUT / 32; ++m) {
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < NIN / 2; ++r) {
-            float a = base[LIDX(r, 0) * STRIDE + 32 * m];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[r], acc, 0, 0, 0);
+        for (int r = 0; r < NIN / 4; ++r) {
+            const float a0 = base[LIDX(r, 0) * STRIDE], a1 = base[LIDX(r + NIN / 4, 0) * STRIDE];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x[r], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x[r + NIN / 4], acc1, 0, 0, 0);
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[k];
+        for (int k = 0; k < 16; ++k) y[k] = acc0[k] + acc1[k];
+    } else {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            acc[m] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < NIN / 2; ++r) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float a = base[LIDX(r, 0) * STRIDE + 32 * m];
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[r], acc[m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k];
     }
 }
 
@@ -266,6 +302,54 @@ __device__ __forceinline__ bool gather_geo(const float* __restrict__ planes, int
     return any;
 }
 
+// backward variant: the upstream (sbar, gbar) of the sample is known before the gather, so the only two
+// combinations of the texels the backward needs are f (for the MLP recompute) and
+//     u = sbar * f + J gbar = sum_corners coef_c * texel_c,   coef_c = w_c sbar + dw_c/dx . gbar
+// (the same coefficient the gradient scatter uses): 32 registers and 2 FMAs per texel value instead of 64 / 4.
+__device__ __forceinline__ bool gather_geo_bwd(const float* __restrict__ planes, int H, int W, float X, float Y,
+                                               float Z, bool valid, float sbar, float gux, float guy, float guz,
+                                               float jscale_u, float jscale_v, int hi, float (&f)[16],
+                                               float (&u)[16], int dbg = 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        f[r] = 0.f;
+        u[r] = 0.f;
+    }
+    bool any = false;
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        Corners c;
+        corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, c);
+        if (!__any(c.any)) continue;
+        any = any || c.any;
+        const float gu = (p == 2 ? guz : gux) * jscale_u, gv = (p == 1 ? guz : guy) * jscale_v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4* t = reinterpret_cast<const f32x4*>(planes + (p * HW + (size_t)c.off[k]) * TT_C) + hi;
+            f32x4 v[4];
+            if (dbg & TT_DBG_NO_GATHER) {
+                const f32x4 z = {c.w[k], c.du[k], c.dv[k], X};
+                v[0] = v[1] = v[2] = v[3] = z;
+            } else {
+                v[0] = t[0];
+                v[1] = t[2];
+                v[2] = t[4];
+                v[3] = t[6];
+            }
+            const float wk = c.w[k], ck = fmaf(c.w[k], sbar, fmaf(c.du[k], gu, c.dv[k] * gv));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[4 * q + e] = fmaf(wk, v[q][e], f[4 * q + e]);
+                    u[4 * q + e] = fmaf(ck, v[q][e], u[4 * q + e]);
+                }
+        }
+    }
+    return any;
+}
+
 // texture planes (v2 = concat over planes): e[48], e[16p + r] <-> channel LIDX(r,hi) of plane p
 __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int H, int W, float X, float Y, float Z,
                                            bool valid, int hi, float (&e)[48], int dbg = 0) {
@@ -310,18 +394,37 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
 // balanced whatever the image size.  Block b runs on XCD b % 8 and every XCD owns one contiguous chunk of items
 // (its texels stay in that XCD's L2).
 struct ItemRange {
-    long long lo, hi;
+    long long lo, hi;  // local item indices of this wave within its XCD's share: lo, lo+stride, ... < hi
     int stride;
+    long long b_lo;    // first ray block of this XCD
+    long long nb;      // number of ray blocks of this XCD
 };
-__device__ __forceinline__ ItemRange item_range(long long n_items) {
+// Every XCD owns a contiguous range of RAY BLOCKS (all chunks of them).  Within the XCD, items are ordered
+// chunk-major: local item li -> chunk li / nb, block b_lo + li % nb, so the waves that run concurrently on one XCD
+// work on neighbouring pixel blocks at the SAME depth range -- a compact slab of space whose texels fit the XCD's
+// 4 MB L2 (block-major order had every XCD touch all depths at once: 42 % L2 hit rate).
+__device__ __forceinline__ ItemRange item_range(long long n_blocks, int n_chunks) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const long long chunk = (n_items + 7) / 8;
+    const long long per = (n_blocks + 7) / 8;
     ItemRange g;
-    const long long lo = xcd * chunk;
-    g.hi = (lo + chunk < n_items) ? lo + chunk : n_items;
+    g.b_lo = xcd * per;
+    const long long b_hi = (g.b_lo + per < n_blocks) ? g.b_lo + per : n_blocks;
+    g.nb = b_hi > g.b_lo ? b_hi - g.b_lo : 0;
+    g.hi = g.nb * n_chunks;
     g.stride = (gridDim.x >> 3) * (blockDim.x >> 6);
-    g.lo = lo + slot * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    g.lo = slot * (blockDim.x >> 6) + (threadIdx.x >> 6);
     return g;
+}
+__device__ __forceinline__ void item_decode(const ItemRange& g, long long li, int order, int n_chunks, long long& b,
+                                            int& ck) {
+    if (order == 0) {  // chunk-major (default)
+        ck = (int)(li / g.nb);
+        b = g.b_lo + (li - (long long)ck * g.nb);
+    } else {  // block-major
+        const long long bl = li / n_chunks;
+        ck = (int)(li - bl * n_chunks);
+        b = g.b_lo + bl;
+    }
 }
 
 struct TileGeom {
@@ -330,6 +433,8 @@ struct TileGeom {
     int image_w, image_h;  // image_w == 0: linear 32-ray strips
     int bpr, bpv;          // 8x4 blocks per image row / per view
     int n_samples, chunk, n_chunks;
+    long long n_blocks;
+    int order;  // 0 chunk-major within an XCD, 1 block-major (TT_ORDER, tuning only)
 };
 
 // ray handled by lane j (0..31) of ray block b

@@ -248,13 +248,14 @@ __global__ __launch_bounds__(256, 2) void k_decode_rays(DecodeRaysParams p) {
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const int S = cfg.n_samples;
-    const ItemRange ir = item_range(p.n_items);
+    const ItemRange ir = item_range(tg.n_blocks, tg.n_chunks);
     const size_t plane_stride = (size_t)6 * cfg.plane_h * cfg.plane_w * TT_C;
 
 #pragma nounroll
     for (long long item = ir.lo; item < ir.hi; item += ir.stride) {
-        const long long b = item / tg.n_chunks;
-        const int ck = (int)(item - b * tg.n_chunks);
+        long long b;
+        int ck;
+        item_decode(ir, item, tg.order, tg.n_chunks, b, ck);
         bool rvalid;
         const long long ray = tile_ray(tg, b, i, rvalid);
         const int view = (int)(ray / cfg.rays_per_view);
@@ -387,7 +388,7 @@ int tt_validate_cfg(const tt_render_cfg* cfg) {
 
 // Fills the tile geometry and picks the chunk length: enough items (>= 8 per wave slot) for balance, chunks as
 // long as possible so consecutive depths of the same rays reuse L1/L2-resident texels.
-long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g) {
+long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g, int default_order) {
     g->n_rays = cfg->n_rays;
     g->rays_per_view = cfg->rays_per_view;
     g->n_samples = cfg->n_samples;
@@ -413,6 +414,9 @@ long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom*
     }
     g->chunk = (cfg->n_samples + n_chunks - 1) / n_chunks;
     g->n_chunks = (cfg->n_samples + g->chunk - 1) / g->chunk;
+    g->n_blocks = n_blocks;
+    g->order = default_order;
+    if (const char* e = getenv("TT_ORDER")) g->order = atoi(e) ? 1 : 0;  // tuning only
     return n_blocks * g->n_chunks;
 }
 
@@ -446,7 +450,7 @@ extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const
     p.sdf_grad = sdf_grad;
     p.features = features;
     const long long slots = 2LL * cus * 4;  // 2 workgroups of 4 waves per CU (LDS 69 KB each)
-    p.n_items = tt_make_geom(cfg, slots, &p.geom);
+    p.n_items = tt_make_geom(cfg, slots, &p.geom, 0);
     long long blocks = 2LL * cus;
     long long need = (p.n_items + 3) / 4;
     if (blocks > need) blocks = need;
@@ -486,7 +490,7 @@ extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, cons
     p.sdf_grad = sdf_grad;
     p.features = features;
     const long long slots = 2LL * cus * 4;
-    p.n_items = tt_make_geom(cfg, slots, &p.geom);
+    p.n_items = tt_make_geom(cfg, slots, &p.geom, 0);
     long long blocks = 2LL * cus;
     long long need = (p.n_items + 3) / 4;
     if (blocks > need) blocks = need;

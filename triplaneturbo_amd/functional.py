@@ -14,6 +14,68 @@ from . import ops
 Tensor = torch.Tensor
 
 
+class LazyOutputs(dict):
+    """The renderer's output dict.  The reference returns a dozen per-sample "training extras" on every call
+    (renderer :532-545) although a given loss configuration reads only a few of them; here they are registered as
+    thunks and materialised on first access (`out["normal"]`, `"normal" in out`, `.keys()`, `.items()` all behave
+    like the eager dict; each thunk runs once, under the grad mode of the render call)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._lazy = {}
+
+    def set_lazy(self, key, fn):
+        self._lazy[key] = fn
+
+    def _materialise(self, key):
+        fn = self._lazy.pop(key)
+        val = fn()
+        super().__setitem__(key, val)
+        return val
+
+    def __getitem__(self, key):
+        if key in self._lazy:
+            return self._materialise(key)
+        return super().__getitem__(key)
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        super().__setitem__(key, value)
+
+    def __contains__(self, key):
+        return key in self._lazy or super().__contains__(key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def _all(self):
+        for k in list(self._lazy):
+            self._materialise(k)
+
+    def keys(self):
+        self._all()
+        return super().keys()
+
+    def items(self):
+        self._all()
+        return super().items()
+
+    def values(self):
+        self._all()
+        return super().values()
+
+    def __iter__(self):
+        self._all()
+        return super().__iter__()
+
+    def __len__(self):
+        return super().__len__() + len(self._lazy)
+
+    def update(self, *a, **k):
+        for key, v in dict(*a, **k).items():
+            self[key] = v
+
+
 def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
                   rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, bg_color: Tensor, camera_distances: Tensor,
                   c2w: Tensor, rc: ops.RenderConfig, training: bool = True,
@@ -34,14 +96,14 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
     comp_rgb = comp_rgb_fg + bg * (1.0 - opacity)  # :439
     if comp_rgb_bg is None:
         comp_rgb_bg = bg
-    out = {
+    out = LazyOutputs({
         "comp_rgb": comp_rgb.view(B, Hh, Ww, -1),
         "comp_rgb_fg": comp_rgb_fg.view(B, Hh, Ww, -1),
         "comp_rgb_bg": comp_rgb_bg.reshape(B, Hh, Ww, -1),
         "opacity": opacity.view(B, Hh, Ww, 1),
         "depth": depth.view(B, Hh, Ww, 1),
         "z_variance": z_variance.view(B, Hh, Ww, 1),
-    }
+    })
     # :452-462
     cd = camera_distances.reshape(-1, 1, 1, 1)
     far = cd + math.sqrt(3.0)
@@ -78,18 +140,39 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
     elif normal_direction != "world":
         raise ValueError(normal_direction)
 
-    if training:  # :532-545
-        t_positions = ((t_starts + t_ends) / 2.0).reshape(-1, 1)
-        t_intervals = (t_ends - t_starts).reshape(-1, 1)
-        ray_indices = torch.arange(n_rays, device=ro.device).unsqueeze(-1).expand(-1, S).reshape(-1)
-        t_dirs = rd[ray_indices]
-        positions = ro[ray_indices] + t_dirs * t_positions
-        sdf_grad = r["sdf_grad"]
-        normal = F.normalize(sdf_grad, dim=-1)
-        sdf = r["sdf"]
-        sdf_bias = (positions ** 2).sum(dim=-1, keepdim=True).sqrt() - rc.sdf_bias_radius
-        out.update(weights=r["weights"], t_points=t_positions, t_intervals=t_intervals, t_dirs=t_dirs,
-                   ray_indices=ray_indices, points=positions, sdf=sdf, sdf_orig=sdf - sdf_bias,
-                   features=r["features"], normal=normal, shading_normal=normal, sdf_grad=sdf_grad,
-                   inv_std=torch.as_tensor(rc.inv_std, device=ro.device))
+    if training:  # :532-545 -- per-sample extras; kernel outputs are eager, derived tensors are lazy
+        grad_mode = torch.is_grad_enabled()
+
+        def lazy(fn):
+            def run():
+                with torch.set_grad_enabled(grad_mode):
+                    return fn()
+            return run
+
+        cache = {}
+
+        def shared(name, fn):
+            if name not in cache:
+                cache[name] = fn()
+            return cache[name]
+
+        t_pos = lambda: shared("t", lambda: ((t_starts + t_ends) / 2.0).reshape(-1, 1))
+        ridx = lambda: shared("ri", lambda: torch.arange(n_rays, device=ro.device).unsqueeze(-1).expand(-1, S).reshape(-1))
+        t_dirs = lambda: shared("td", lambda: rd[ridx()])
+        points = lambda: shared("p", lambda: ro[ridx()] + t_dirs() * t_pos())
+        normal = lambda: shared("n", lambda: F.normalize(r["sdf_grad"], dim=-1))
+        out["weights"] = r["weights"]
+        out["sdf"] = r["sdf"]
+        out["features"] = r["features"]
+        out["sdf_grad"] = r["sdf_grad"]
+        out.set_lazy("t_points", lazy(t_pos))
+        out.set_lazy("t_intervals", lazy(lambda: (t_ends - t_starts).reshape(-1, 1)))
+        out.set_lazy("t_dirs", lazy(t_dirs))
+        out.set_lazy("ray_indices", lazy(ridx))
+        out.set_lazy("points", lazy(points))
+        out.set_lazy("sdf_orig", lazy(lambda: r["sdf"] - ((points() ** 2).sum(dim=-1, keepdim=True).sqrt()
+                                                          - rc.sdf_bias_radius)))
+        out.set_lazy("normal", lazy(normal))
+        out.set_lazy("shading_normal", lazy(normal))
+        out["inv_std"] = torch.as_tensor(rc.inv_std, device=ro.device)
     return out
