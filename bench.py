@@ -117,13 +117,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # (two ranks may share a GPU in the 1-GPU smoke test)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("TT_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for smoke tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from triplaneturbo_amd import functional, ops
     from triplaneturbo_amd.parallel import allreduce_mlp_grads
@@ -178,8 +184,16 @@ def main():
                           "tflops": round(flops[k] * n_samples / (ms * 1e-3) / 1e12, 3)}
         dom = max(ksum, key=lambda k: ksum[k][0])
         ach = flops[dom] * n_samples / (ksum[dom][0] * 1e-3) / 1e12
+        traffic = None  # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        try:
+            tb = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_bytes.json")))
+            key = {"tt_render_fwd": "k_decode_rays", "tt_render_bwd_geo": "k_decode_bwd_geo",
+                   "tt_render_bwd_tex": "k_decode_bwd_tex"}[dom]
+            traffic = next(v for k, v in tb.items() if key in k)
+        except Exception:
+            pass
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "avg_kernel_ms": round(ksum[dom][0], 4),
                     "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32); algorithmic FLOP/sample x samples per launch"}
         # sampling/marching stages against the HBM roofline (gathers fwd + plane-grad scatter bwd)
@@ -198,7 +212,7 @@ def main():
                                    "128 uniform samples on [0.1,4.0], fwd + bwd of the G6 loss "
                                    "(d/d planes + d/d 6 MLP matrices, second-order normal path included)",
                        "rays_per_gpu": n_rays, "samples_per_ray": S, "parallelism": f"dp{world}",
-                       "loss": float(loss)},
+                       "loss": float(loss.detach())},
             "roofline": roofline, "roofline_hbm": hbm, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,83 @@
+"""GPU tests at BASELINE.json's full size (planes 256^2, 256x256 rays, 128 samples): size-independent properties
+plus oracle parity on a subset of rays (per-ray outputs do not depend on the other rays)."""
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bench
+    from triplaneturbo_amd import ops
+    inp = bench.make_inputs(0, torch.device("cuda", 0))
+    return bench, ops, inp
+
+
+def test_forward_properties_and_subset_parity(full):
+    bench, ops, inp = full
+    rc = ops.RenderConfig()
+    ro, rd = inp["ro"].reshape(-1, 3), inp["rd"].reshape(-1, 3)
+    packed = ops.planes_pack(inp["cache"].detach())
+    sw, fw = [w.detach() for w in inp["sw"]], [w.detach() for w in inp["fw"]]
+    r = ops.render_forward_raw(packed, sw, fw, ro, rd, inp["ts"], inp["te"], 65536, rc, image_w=256)
+    S = 128
+    w = r["weights"].view(-1, S)
+    tr = r["trans"].view(-1, S)
+    # weights partition opacity; transmittance starts at 1 and never increases; everything finite
+    torch.testing.assert_close(w.sum(1, keepdim=True), r["opacity"], rtol=1e-5, atol=1e-6)
+    # (the wave-wide product scan multiplies in tree order: monotone up to one ulp)
+    assert torch.all(tr[:, 0] == 1.0) and torch.all(tr[:, 1:] <= tr[:, :-1] * (1 + 4e-7) + 1e-37)
+    assert all(torch.isfinite(v).all() for v in r.values())
+    assert (r["opacity"] >= 0).all() and (r["opacity"] <= 1 + 1e-5).all()
+    # the tiling must not matter: 8x4 pixel tiles vs linear 32-ray strips give the same image (same per-sample math)
+    r2 = ops.render_forward_raw(packed, sw, fw, ro, rd, inp["ts"], inp["te"], 65536, rc, image_w=0)
+    for k in ("opacity", "rgb_fg", "depth", "sdf", "features"):
+        torch.testing.assert_close(r[k], r2[k], rtol=0, atol=0)
+    # oracle parity on a scattered subset of rays (fp64 and fp32 restatements)
+    sel = torch.arange(0, 65536, 1021)[:64]
+    c = inp["cache"].detach().cpu()
+    swc, fwc = [x.cpu() for x in sw], [x.cpu() for x in fw]
+    roc, rdc = ro.cpu()[sel].view(1, 1, -1, 3), rd.cpu()[sel].view(1, 1, -1, 3)
+    tsc, tec = inp["ts"].cpu()[sel], inp["te"].cpu()[sel]
+    kw = dict(create_graph=False, training=True)
+    o32 = O.render(c, swc, fwc, roc, rdc, tsc, tec, torch.ones(3), inp["cd"].cpu(), inp["c2w"].cpu(), **kw)
+    d = torch.float64
+    o64 = O.render(c.to(d), [x.to(d) for x in swc], [x.to(d) for x in fwc], roc.to(d), rdc.to(d), tsc.to(d), tec.to(d),
+                   torch.ones(3, dtype=d), inp["cd"].cpu().to(d), inp["c2w"].cpu().to(d), **kw)
+    for key, okey in (("opacity", "opacity"), ("depth", "depth"), ("rgb_fg", "comp_rgb_fg"), ("z_variance", "z_variance")):
+        got = r[key].cpu()[sel].double().reshape(-1)
+        e_hip = (got - o64[okey].reshape(-1)).abs().max().item()
+        e_cpu = (o32[okey].double().reshape(-1) - o64[okey].reshape(-1)).abs().max().item()
+        assert e_hip <= max(4 * e_cpu, 2e-5), (key, e_hip, e_cpu)
+
+
+def test_backward_linear_in_rays_full_size(full):
+    """d loss / d(planes, weights) over all 65 536 rays == sum over two disjoint ray subsets (atomics, window
+    combining and persistent accumulators may not drop or double count anything)."""
+    bench, ops, inp = full
+    rc = ops.RenderConfig()
+    ro, rd = inp["ro"].reshape(-1, 3), inp["rd"].reshape(-1, 3)
+    n = ro.shape[0]
+    g = torch.Generator().manual_seed(0)
+    pr = torch.randn(n, 3, generator=g).cuda()
+
+    def grads(lo, hi, image_w):
+        c = inp["cache"].detach().clone().requires_grad_(True)
+        sws = [w.detach().clone().requires_grad_(True) for w in inp["sw"]]
+        fws = [w.detach().clone().requires_grad_(True) for w in inp["fw"]]
+        r = ops.render_samples(c, sws, fws, ro[lo:hi], rd[lo:hi], inp["ts"][lo:hi], inp["te"][lo:hi], hi - lo, rc,
+                               image_w=image_w)
+        loss = (r["rgb_fg"] * pr[lo:hi]).sum() + r["opacity"].sum() + ((r["sdf_grad"].norm(dim=-1) - 1) ** 2).sum()
+        return torch.autograd.grad(loss, [c] + sws + fws)
+
+    full_g = grads(0, n, 256)
+    half = 128 * 256  # first 128 image rows
+    a, b = grads(0, half, 256), grads(half, n, 256)
+    for x, y, z in zip(full_g, a, b):
+        rel = ((y + z).double() - x.double()).norm() / x.double().norm()
+        assert rel < 2e-5, rel
