@@ -19,6 +19,7 @@
  *                            VanillaMLP networks.py:67-104, get_shifted_sdf :131-154, analytic normal :329-335
  *                            -> aten grid_sampler_2d_backward via cuda_gridsample.py:55-58)
  *                           and forward_sdf :353-373 (flags without TT_Q_TEX / TT_Q_NORMAL).
+ *   tt_query_field          forward_field :375-394 (sdf + deformation head; mesh renderer / exporter grid query)
  *   tt_decode_rays          the geometry call of prop_sigma_fn (renderer :243-299 -> few_step...:273-306, sdf only)
  *   tt_render_fwd           GenerativeSpaceSDFVolumeRenderer._forward
  *                           generative_space_sdf_volume_renderer.py:326-431,467-472 (positions, geometry,
@@ -111,6 +112,14 @@ int tt_query_points(const float* packed, const tt_mlp_weights* w, const float* p
                     int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
                     float radius, float sdf_bias_radius, int32_t flags, float* out_sdf, float* out_sdf_grad,
                     float* out_features, void* stream);
+
+/* Implicit-field query for isosurface extraction (forward_field, few_step...:375-394; callers
+ * generative_space_mesh_rasterize_renderer.py:428-452 and triplaneturbo_executable/utils/mesh_exporter.py:78-105):
+ * sdf (n_batch*n_points) and deformation (n_batch*n_points,3) from the geometry planes only.
+ * `w`: sdf net in w1..w3, DEFORMATION net (32->64->64->3, few_step...:113-122) in v1..v3. */
+int tt_query_field(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
+                   int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
+                   float radius, float sdf_bias_radius, float* out_sdf, float* out_deformation, void* stream);
 
 /* Decode only, along rays: sdf [+ sdf_grad if TT_Q_NORMAL] [+ features if TT_Q_TEX] at the mid-points of the
  * intervals (n_rays,S).  The importance sampler's proposal pass (prop_sigma_fn, renderer :243-299) uses flags = 0. */

@@ -140,3 +140,22 @@ def test_geometry_queries_match_oracle(dev):
     assert d is None and f.shape == (4, 100, 1)
     ex = g.export(pts[:1].to(dev), cache[:1].to(dev))
     torch.testing.assert_close(ex["features"].cpu().reshape(-1, 3), want["features"][:100], rtol=2e-4, atol=2e-5)
+
+
+def test_forward_field_with_deformation_head(dev):
+    """the mesh renderer / exporter grid query (sdf + deformation_network, few_step...:375-394)."""
+    torch.manual_seed(7)
+    g = tt.find("few-step-triplane-dual-stable-diffusion")({"isosurface_deformable_grid": True}).to(dev)
+    gen = torch.Generator().manual_seed(8)
+    cache = torch.randn(1, 6, 32, 32, 32, generator=gen) * 0.5
+    # a 12^3 grid like the isosurface helper's vertices, slightly beyond the box
+    lin = torch.linspace(-1.1, 1.1, 12)
+    pts = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(1, -1, 3)
+    sdf, deform = g.forward_field(pts.to(dev), cache.to(dev))
+    assert sdf.shape == (1, 1728, 1) and deform.shape == (1, 1728, 3)
+    sw, fw = _weights(g)
+    dw = [w.detach().cpu() for w in g.deformation_network.weights()]
+    want = O.geometry_forward(pts, cache, sw, fw, output_normal=False)
+    torch.testing.assert_close(sdf.cpu().reshape(-1, 1), want["sdf"], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(deform.cpu().reshape(-1, 3), O.vanilla_mlp(want["enc_geo"], dw), rtol=2e-4, atol=2e-5)
+    assert list(g.state_dict().keys())[-3:] == [f"deformation_network.layers.{i}.weight" for i in (0, 2, 4)]

@@ -168,3 +168,27 @@ def test_ops_refuse_cpu_tensors():
     from triplaneturbo_amd import ops
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.planes_pack(torch.zeros(1, 6, 32, 8, 8))
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
+    """Argument validation happens before any HIP call, so the error paths are testable without a device:
+    null pointers / inconsistent shapes -> TT_ERR_BAD_ARG (-1), unsupported shapes -> TT_ERR_UNSUPPORTED (-2)."""
+    _lib.build()
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(8)  # never dereferenced: validation fails first
+    assert lib.tt_planes_pack(null, one, 1, 8, 8, null) == -1
+    assert lib.tt_planes_pack(one, one, 1, 8, 16, null) == -2  # non-square planes (rotation v1 transposes)
+    assert lib.tt_planes_unpack_grad(one, null, 1, 8, 8, null) == -1
+    w = _lib.MlpWeights(one, one, one, one, one, one)
+    assert lib.tt_query_points(one, ctypes.byref(w), one, 3, 10, 2, 2, 8, 8, 1.0, 0.5, 3, one, one, one, null) == -1
+    cfg = _lib.RenderCfg(1, 1, 8, 8, 16, 4, 16, 1.0, 0.5, 100.0, 1.0, 1.0, 0, 0)
+    bad = _lib.RenderCfg(1, 1, 8, 8, 16, 4, 17, 1.0, 0.5, 100.0, 1.0, 1.0, 0, 0)  # n_rays != views*rays_per_view
+    args = [one] * 11
+    assert lib.tt_render_fwd(one, ctypes.byref(w), one, one, one, one, ctypes.byref(bad), *args, null) == -1
+    assert lib.tt_render_fwd(one, ctypes.byref(w), one, one, one, one, ctypes.byref(cfg), *([null] + [one] * 10),
+                             null) == -1
+    assert lib.tt_decode_rays(one, ctypes.byref(w), one, one, one, one, ctypes.byref(cfg), 1, one, null, null,
+                              null) == -1  # TT_Q_NORMAL without an sdf_grad buffer
+    assert lib.tt_grid_sample_2d_grad2(one, one, one, one, one, 1, 4, 8, 8, 5, 1, 0, one, one, one, null) == -2
+    assert b"unsupported" in lib.tt_strerror(-2)

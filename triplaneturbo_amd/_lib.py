@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomic
 # every symbol include/tt_abi.h declares (tests check the header and this list agree)
 SYMBOLS = [
     "tt_strerror", "tt_abi_version", "tt_planes_pack", "tt_planes_unpack_grad", "tt_query_points",
-    "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2",
+    "tt_query_field", "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2",
 ]
 
 
@@ -103,6 +103,7 @@ def load() -> ctypes.CDLL:
                                     _I32, _P, _P, _P, _P]
     lib.tt_render_fwd.argtypes = [_P, ctypes.POINTER(MlpWeights), _P, _P, _P, _P, ctypes.POINTER(RenderCfg)] + [_P] * 11
     _cfgp, _wp = ctypes.POINTER(RenderCfg), ctypes.POINTER(MlpWeights)
+    lib.tt_query_field.argtypes = [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P]
     lib.tt_decode_rays.argtypes = [_P, _wp, _P, _P, _P, _P, _cfgp, _I32, _P, _P, _P, _P]
     optional = {
         "tt_render_bwd_geo": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 14 + [_P, _P, _wp, _P],

@@ -218,6 +218,84 @@ __global__ __launch_bounds__(256, 2) void k_query_points(QueryParams p) {
 }
 
 // =====================================================================================================
+// tt_query_field: sdf + deformation head on the geometry planes (forward_field, few_step...:375-394)
+// =====================================================================================================
+#define OFF_D1 LDS_GEO_FLOATS
+#define OFF_D2 (OFF_D1 + 64 * W1S)
+#define OFF_D3 (OFF_D2 + 64 * W2S)
+#define LDS_FIELD_FLOATS (OFF_D3 + 3 * 64)
+
+struct QueryFieldParams {
+    const float* packed;
+    MlpPtrs w;  // sdf net in w1..w3, deformation net in v1..v3 (32->64->64->3)
+    const float* points;
+    int n_batch;
+    long long n_points;
+    int views_per_prompt;
+    int H, W;
+    float radius, bias_radius;
+    float* out_sdf;
+    float* out_def;
+};
+
+__global__ __launch_bounds__(256, 2) void k_query_field(QueryFieldParams p) {
+    __shared__ __attribute__((aligned(16))) float L[LDS_FIELD_FLOATS];
+    {
+        MlpPtrs w = p.w;
+        lds_load_geo_weights(L, w);
+        lds_load_matrix(L + OFF_D1, w.v1, 64, 32, W1S);
+        lds_load_matrix(L + OFF_D2, w.v2, 64, 64, W2S);
+        lds_load_matrix(L + OFF_D3, w.v3, 3, 64, 64);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const long long tiles_per_batch = (p.n_points + TT_TILE - 1) / TT_TILE;
+    const long long n_tiles = tiles_per_batch * p.n_batch;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const size_t plane_stride = (size_t)6 * p.H * p.W * TT_C;
+#pragma nounroll
+    for (long long tile = wave0; tile < n_tiles; tile += n_waves) {
+        const int b = (int)(tile / tiles_per_batch);
+        const long long n = (tile - (long long)b * tiles_per_batch) * TT_TILE + i;
+        const bool valid = n < p.n_points;
+        const long long idx = (long long)b * p.n_points + (valid ? n : 0);
+        const float* pbase = p.packed + (size_t)(b / p.views_per_prompt) * plane_stride;
+        const float px = p.points[idx * 3 + 0], py = p.points[idx * 3 + 1], pz = p.points[idx * 3 + 2];
+        const float X = scale_coord(px, p.radius), Y = scale_coord(py, p.radius), Z = scale_coord(pz, p.radius);
+        float f[16], jx[16], jy[16], jz[16];
+        const bool any = __any(gather_geo<false>(pbase, p.H, p.W, X, Y, Z, valid, 0.f, 0.f, hi, f, jx, jy, jz));
+        float s0 = 0.f, d[3] = {0.f, 0.f, 0.f};
+        if (any) {  // exact skip otherwise: bias-free MLPs of a zero vector
+            float h1[32], h2[32];
+            mv_fwd<64, 32>(L + OFF_W1, f, h1, i, hi);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
+            mv_fwd<64, 64>(L + OFF_W2, h1, h2, i, hi);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
+            s0 = dot_lds<64>(L + OFF_W3, h2, hi);
+            mv_fwd<64, 32>(L + OFF_D1, f, h1, i, hi);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
+            mv_fwd<64, 64>(L + OFF_D2, h1, h2, i, hi);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) d[o] = dot_lds<64>(L + OFF_D3 + 64 * o, h2, hi);
+        }
+        float nrm;
+        const float sdf = s0 + sphere_bias(px, py, pz, p.bias_radius, nrm);
+        if (valid && hi == 0) {
+            p.out_sdf[idx] = sdf;
+            p.out_def[idx * 3 + 0] = d[0];
+            p.out_def[idx * 3 + 1] = d[1];
+            p.out_def[idx * 3 + 2] = d[2];
+        }
+    }
+}
+
+// =====================================================================================================
 // K1: decode every sample of every ray (tiles of 32 adjacent rays x one sample index, chunks of CH indices)
 // =====================================================================================================
 struct DecodeRaysParams {
@@ -505,5 +583,39 @@ extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, cons
         hipLaunchKernelGGL((k_decode_rays<false, true>), grid, blk, 0, s, p);
     else
         hipLaunchKernelGGL((k_decode_rays<false, false>), grid, blk, 0, s, p);
+    return tt_check_launch();
+}
+
+// sdf + deformation on the geometry planes.  `w`: sdf net in w1..w3 and the DEFORMATION net (32->64->64->3,
+// few_step...:113-122) in v1..v3.
+extern "C" int tt_query_field(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
+                              int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h,
+                              int32_t plane_w, float radius, float sdf_bias_radius, float* out_sdf,
+                              float* out_deformation, void* stream) {
+    if (!packed || !w || !points || !out_sdf || !out_deformation || n_batch <= 0 || n_points <= 0 || n_prompts <= 0 ||
+        views_per_prompt <= 0)
+        return TT_ERR_BAD_ARG;
+    if (n_batch != n_prompts * views_per_prompt || !(radius > 0.f)) return TT_ERR_BAD_ARG;
+    if (plane_h != plane_w || plane_h <= 0) return TT_ERR_UNSUPPORTED;
+    if (!w->w1 || !w->w2 || !w->w3 || !w->v1 || !w->v2 || !w->v3) return TT_ERR_BAD_ARG;
+    QueryFieldParams p;
+    p.packed = packed;
+    p.w = to_ptrs(w);
+    p.points = points;
+    p.n_batch = n_batch;
+    p.n_points = n_points;
+    p.views_per_prompt = views_per_prompt;
+    p.H = plane_h;
+    p.W = plane_w;
+    p.radius = radius;
+    p.bias_radius = sdf_bias_radius;
+    p.out_sdf = out_sdf;
+    p.out_def = out_deformation;
+    int cus = tt_num_cus();
+    if (cus <= 0) return TT_ERR_DEVICE;
+    long long n_tiles = ((n_points + TT_TILE - 1) / TT_TILE) * n_batch;
+    long long blocks = (n_tiles + 3) / 4;
+    if (blocks > 2LL * cus) blocks = 2LL * cus;
+    hipLaunchKernelGGL(k_query_field, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return tt_check_launch();
 }

@@ -135,10 +135,18 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
 
     @torch.no_grad()
     def forward_field(self, points: Tensor, space_cache: Tensor):
-        """few_step...:375-394.  The deformation head is a SURVEY 8(f) 'next' row and is not built yet."""
-        if self.cfg.isosurface_deformable_grid:
-            raise NotImplementedError("deformation_network query (SURVEY.md 8f rank 1) is not implemented yet")
-        return self.forward_sdf(points, space_cache), None
+        """few_step...:375-394: sdf (*N,1) and, with isosurface_deformable_grid, deformation (*N,3)."""
+        if not self.cfg.isosurface_deformable_grid:
+            return self.forward_sdf(points, space_cache), None
+        B = points.shape[0]
+        pts = points.reshape(B, -1, 3)
+        packed = ops.planes_pack(space_cache.detach())
+        sw, _ = self.mlp_weights()
+        sdf, deform = ops.query_field(packed, [w.detach() for w in sw],
+                                      [w.detach() for w in self.deformation_network.weights()], pts.float(),
+                                      views_per_prompt=B // space_cache.shape[0], radius=self.cfg.radius,
+                                      sdf_bias_radius=float(self.cfg.sdf_bias_params))
+        return sdf.reshape(*points.shape[:-1], 1), deform.reshape(*points.shape[:-1], 3)
 
     def forward_level(self, field: Tensor, threshold: float) -> Tensor:
         return field - threshold

@@ -139,6 +139,25 @@ def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Seque
     return sdf, grad, feat
 
 
+def query_field(packed: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tensor], points: Tensor,
+                views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5):
+    """sdf (B*N,1) and deformation (B*N,3) from the geometry planes (forward_field)."""
+    packed = _chk(packed, "packed")
+    points = _chk(points, "points")
+    B, N, _ = points.shape
+    P, _, H, W, _ = packed.shape
+    sw = [_chk(sdf_w[0], "sdf w1", (64, 32)), _chk(sdf_w[1], "sdf w2", (64, 64)), _chk(sdf_w[2], "sdf w3", (1, 64))]
+    dw = [_chk(deform_w[0], "def d1", (64, 32)), _chk(deform_w[1], "def d2", (64, 64)),
+          _chk(deform_w[2], "def d3", (3, 64))]
+    wst = _lib.MlpWeights(*[_ptr(t) for t in sw + dw])
+    sdf = torch.empty((B * N, 1), device=points.device, dtype=torch.float32)
+    deform = torch.empty((B * N, 3), device=points.device, dtype=torch.float32)
+    st = _lib.load().tt_query_field(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, views_per_prompt, H, W,
+                                    radius, sdf_bias_radius, _ptr(sdf), _ptr(deform), _stream())
+    _lib.check(st, "tt_query_field")
+    return sdf, deform
+
+
 def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, rc: RenderConfig,
               per_sample: bool, image_w: int = 0) -> "_lib.RenderCfg":
     P, _, H, W, _ = packed.shape
