@@ -131,6 +131,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from triplaneturbo_amd import _lib
+    if local_rank == 0:
+        _lib.build()  # in-tree hipcc build; no-op when libtt_hip.so is up to date
+    if world > 1:
+        dist.barrier()
     from triplaneturbo_amd import functional, ops
     from triplaneturbo_amd.parallel import allreduce_mlp_grads
 

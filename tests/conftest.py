@@ -17,3 +17,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """Explicit build step (NOT a fallback): the HIP library is compiled in-tree with hipcc before any test uses it;
+    a no-op when triplaneturbo_amd/libtt_hip.so is newer than its sources."""
+    from triplaneturbo_amd import _lib
+    _lib.build()
+    yield
