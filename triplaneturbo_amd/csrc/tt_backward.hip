@@ -112,7 +112,8 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
     for (int q = 0; q < 4; ++q) {
         if ((q >> 1) == hi && coef[q] != 0.f) {
             int old = -2;
-            if (!(flags & TT_DBG_NO_COMBINE)) old = atomicCAS(&tags[hs[q]], -1, abs_off[q]);
+            if (flags & TT_DBG_NO_CLAIM) old = -1;
+            else if (!(flags & TT_DBG_NO_COMBINE)) old = atomicCAS(&tags[hs[q]], -1, abs_off[q]);
             if (old == -1 || old == abs_off[q]) {
                 M[hs[q] * MS + i] = coef[q];
                 wrote |= 1 << q;
@@ -131,6 +132,7 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
         for (int t4 = 0; t4 < 4; ++t4)
             a4[m][t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
     f32x16 acc0 = ZERO16, acc1 = ZERO16;
+    if (!(flags & TT_DBG_NO_SCATTER_MFMA))
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const float b = Qs[(t + 16 * hi) * 33 + i];
@@ -250,8 +252,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                         Z = scale_coord(pz, cfg.radius);
             // ---- recompute the geometry decode ----
             float f[16], u[16];  // u = sbar f + J gbar
-            const bool any =
-                __any(gather_geo_bwd(pbase, H, W, X, Y, Z, rvalid, sbar, gbx, gby, gbz, ju, jv, hi, f, u, cfg.flags));
+            Corners cs[3];
+            float coefs[3][4];   // per (plane, corner): w sbar + dw/dx . gbar -- gather AND scatter coefficient
+            const bool any = __any(gather_geo_bwd(pbase, H, W, X, Y, Z, rvalid, sbar, gbx, gby, gbz, ju, jv, hi, f, u,
+                                                  cs, coefs, cfg.flags));
             if (!any) continue;  // exact: no in-bounds texel => f = J = 0, every mask false
             float h1[32], h2[32], a2[32], a1[32], q[16];
             mv_fwd<64, 32>(L + OFF_W1, f, h1, i, hi);
@@ -311,17 +315,13 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                     for (int r = 0; r < 16; ++r) Qs[i * 33 + LIDX(r, hi)] = q[r];
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
-                        Corners c;
-                        corners_setup(PLANE_U(pl, X, Y, Z), PLANE_V(pl, X, Y, Z), H, W, rvalid, c);
-                        const float gu = (pl == 2 ? gbz : gbx) * ju, gv = (pl == 1 ? gbz : gby) * jv;
-                        float coef[4];
+                        if (!__any(cs[pl].any)) continue;  // exact: every coefficient of this plane is 0
                         int aoff[4];
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            coef[q4] = fmaf(c.w[q4], sbar, fmaf(c.du[q4], gu, c.dv[q4] * gv));
-                            aoff[q4] = (int)(pofs / TT_C) + (int)(pl * HW) + c.off[q4];
-                        }
-                        scatter_plane<0, 16>(p.grad_packed, Qs, q, coef, aoff, c.hs, Xs, tags, i, hi, cfg.flags);
+                        for (int q4 = 0; q4 < 4; ++q4)
+                            aoff[q4] = (int)(pofs / TT_C) + (int)(pl * HW) + cs[pl].off[q4];
+                        scatter_plane<0, 16>(p.grad_packed, Qs, q, coefs[pl], aoff, cs[pl].hs, Xs, tags, i, hi,
+                                             cfg.flags);
                     }
                 }
             }

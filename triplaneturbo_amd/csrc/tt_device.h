@@ -29,6 +29,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TT_DBG_NO_STORE 0x1000
 #define TT_DBG_NO_COMBINE 0x2000
 #define TT_DBG_NO_GLOBAL_ATOMIC 0x4000
+#define TT_DBG_NO_SCATTER_MFMA 0x8000
+#define TT_DBG_NO_CLAIM 0x10000
 
 #define TT_C 32
 #define TT_HID 64
@@ -309,7 +311,7 @@ __device__ __forceinline__ bool gather_geo(const float* __restrict__ planes, int
 __device__ __forceinline__ bool gather_geo_bwd(const float* __restrict__ planes, int H, int W, float X, float Y,
                                                float Z, bool valid, float sbar, float gux, float guy, float guz,
                                                float jscale_u, float jscale_v, int hi, float (&f)[16],
-                                               float (&u)[16], int dbg = 0) {
+                                               float (&u)[16], Corners (&cs)[3], float (&coefs)[3][4], int dbg = 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         f[r] = 0.f;
@@ -319,11 +321,13 @@ __device__ __forceinline__ bool gather_geo_bwd(const float* __restrict__ planes,
     const size_t HW = (size_t)H * W;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        Corners c;
+        Corners& c = cs[p];  // kept for the gradient scatter of the same tile
         corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, c);
+        const float gu = (p == 2 ? guz : gux) * jscale_u, gv = (p == 1 ? guz : guy) * jscale_v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) coefs[p][k] = fmaf(c.w[k], sbar, fmaf(c.du[k], gu, c.dv[k] * gv));
         if (!__any(c.any)) continue;
         any = any || c.any;
-        const float gu = (p == 2 ? guz : gux) * jscale_u, gv = (p == 1 ? guz : guy) * jscale_v;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const f32x4* t = reinterpret_cast<const f32x4*>(planes + (p * HW + (size_t)c.off[k]) * TT_C) + hi;
@@ -337,7 +341,7 @@ __device__ __forceinline__ bool gather_geo_bwd(const float* __restrict__ planes,
                 v[2] = t[4];
                 v[3] = t[6];
             }
-            const float wk = c.w[k], ck = fmaf(c.w[k], sbar, fmaf(c.du[k], gu, c.dv[k] * gv));
+            const float wk = c.w[k], ck = coefs[p][k];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
