@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 2
+#define TT_ABI_VERSION 4
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -85,8 +85,15 @@ typedef struct {
     float cos_anneal_ratio;    /* neus_volume_renderer.py:101-104 */
     float rgb_grad_shrink;     /* renderer :397-400 (backward only) */
     int32_t flags;             /* TT_R_* */
-    int32_t image_w;           /* rays of a view form an image_w x (rays_per_view/image_w) image (8x4 pixel tiles);
-                                  0 = unknown: tiles are 32 consecutive rays */
+    int32_t image_w;           /* rays of a view form an image_w x (rays_per_view/image_w) image (pixel-block tiles);
+                                  0 = unknown: tiles are runs of consecutive rays */
+    int32_t tile_sb;           /* consecutive samples of one ray per 32-sample tile: 1, 2, 4, ... 32; 0 = default (1).
+                                  1 suits evenly spaced samples; 4 suits importance sampling, where consecutive samples
+                                  of a ray share texels and are then combined inside the tile (performance only:
+                                  results do not depend on it beyond fp32 summation order) */
+    int32_t grad_copies;       /* backward: grad_packed holds this many privatised copies (copies,P,6,H,W,32), each
+                                  workgroup scatters into one of them and tt_planes_unpack_grad sums them; spreads
+                                  same-texel atomics.  0/1 = a single copy */
 } tt_render_cfg;
 
 #define TT_R_PER_SAMPLE 1 /* also write per-sample sdf / sdf_grad / features (training extras, renderer :532-545) */
@@ -101,9 +108,10 @@ int tt_abi_version(void);
 /* space_cache (P,6,32,H,W) NCHW  ->  packed (P,6,H,W,32), planes re-oriented per rotate_planes "v1". */
 int tt_planes_pack(const float* space_cache, float* packed, int32_t n_prompts, int32_t plane_h, int32_t plane_w,
                    void* stream);
-/* grad wrt packed (P,6,H,W,32) -> grad wrt space_cache (P,6,32,H,W); overwrites dst. */
+/* grad wrt packed, n_copies privatised copies (n_copies,P,6,H,W,32) -> their sum as grad wrt space_cache
+ * (P,6,32,H,W); overwrites dst. */
 int tt_planes_unpack_grad(const float* grad_packed, float* grad_space_cache, int32_t n_prompts, int32_t plane_h,
-                          int32_t plane_w, void* stream);
+                          int32_t plane_w, int32_t n_copies, void* stream);
 
 /* Per-point decode.  points (n_batch, n_points, 3) world units; batch b reads prompt b / views_per_prompt.
  * out_sdf (n_batch*n_points), out_sdf_grad (n_batch*n_points,3) [if TT_Q_NORMAL], out_features (.,3) [if TT_Q_TEX].

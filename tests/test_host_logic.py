@@ -139,7 +139,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == 2
+    assert lib.tt_abi_version() == 4
     assert b"bad argument" in lib.tt_strerror(-1)
 
 
@@ -149,9 +149,9 @@ def test_ctypes_struct_layout_matches_header(tmp_path):
 #include <stddef.h>
 #include "tt_abi.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(tt_render_cfg), offsetof(tt_render_cfg, n_rays),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tt_render_cfg), offsetof(tt_render_cfg, n_rays),
          offsetof(tt_render_cfg, radius), offsetof(tt_render_cfg, flags), offsetof(tt_render_cfg, image_w),
-         sizeof(tt_mlp_weights), sizeof(tt_mlp_grads));
+         offsetof(tt_render_cfg, grad_copies), sizeof(tt_mlp_weights), sizeof(tt_mlp_grads));
   return 0; }'''
     src = tmp_path / "t.c"
     src.write_text(code)
@@ -159,7 +159,7 @@ int main(void) {
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     c = _lib.RenderCfg
-    got = [ctypes.sizeof(c), c.n_rays.offset, c.radius.offset, c.flags.offset, c.image_w.offset,
+    got = [ctypes.sizeof(c), c.n_rays.offset, c.radius.offset, c.flags.offset, c.image_w.offset, c.grad_copies.offset,
            ctypes.sizeof(_lib.MlpWeights), ctypes.sizeof(_lib.MlpWeights)]
     assert [int(x) for x in out] == got
 
@@ -179,11 +179,11 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     one = ctypes.c_void_p(8)  # never dereferenced: validation fails first
     assert lib.tt_planes_pack(null, one, 1, 8, 8, null) == -1
     assert lib.tt_planes_pack(one, one, 1, 8, 16, null) == -2  # non-square planes (rotation v1 transposes)
-    assert lib.tt_planes_unpack_grad(one, null, 1, 8, 8, null) == -1
+    assert lib.tt_planes_unpack_grad(one, null, 1, 8, 8, 1, null) == -1
     w = _lib.MlpWeights(one, one, one, one, one, one)
     assert lib.tt_query_points(one, ctypes.byref(w), one, 3, 10, 2, 2, 8, 8, 1.0, 0.5, 3, one, one, one, null) == -1
-    cfg = _lib.RenderCfg(1, 1, 8, 8, 16, 4, 16, 1.0, 0.5, 100.0, 1.0, 1.0, 0, 0)
-    bad = _lib.RenderCfg(1, 1, 8, 8, 16, 4, 17, 1.0, 0.5, 100.0, 1.0, 1.0, 0, 0)  # n_rays != views*rays_per_view
+    cfg = _lib.RenderCfg(1, 1, 8, 8, 16, 4, 16, 1.0, 0.5, 100.0, 1.0, 1.0, 0, 0, 0, 1)
+    bad = _lib.RenderCfg(1, 1, 8, 8, 16, 4, 17, 1.0, 0.5, 100.0, 1.0, 1.0, 0, 0, 0, 1)  # n_rays != views*rays_per_view
     args = [one] * 11
     assert lib.tt_render_fwd(one, ctypes.byref(w), one, one, one, one, ctypes.byref(bad), *args, null) == -1
     assert lib.tt_render_fwd(one, ctypes.byref(w), one, one, one, one, ctypes.byref(cfg), *([null] + [one] * 10),

@@ -73,7 +73,7 @@ class RenderCfg(ctypes.Structure):
         ("n_prompts", _I32), ("views_per_prompt", _I32), ("plane_h", _I32), ("plane_w", _I32),
         ("rays_per_view", _I32), ("n_samples", _I32), ("n_rays", _I64), ("radius", _F),
         ("sdf_bias_radius", _F), ("inv_std", _F), ("cos_anneal_ratio", _F), ("rgb_grad_shrink", _F),
-        ("flags", _I32), ("image_w", _I32),
+        ("flags", _I32), ("image_w", _I32), ("tile_sb", _I32), ("grad_copies", _I32),
     ]
 
 
@@ -98,7 +98,7 @@ def load() -> ctypes.CDLL:
     lib.tt_strerror.argtypes = [ctypes.c_int]
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_planes_pack.argtypes = [_P, _P, _I32, _I32, _I32, _P]
-    lib.tt_planes_unpack_grad.argtypes = [_P, _P, _I32, _I32, _I32, _P]
+    lib.tt_planes_unpack_grad.argtypes = [_P, _P, _I32, _I32, _I32, _I32, _P]
     lib.tt_query_points.argtypes = [_P, ctypes.POINTER(MlpWeights), _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F,
                                     _I32, _P, _P, _P, _P]
     lib.tt_render_fwd.argtypes = [_P, ctypes.POINTER(MlpWeights), _P, _P, _P, _P, ctypes.POINTER(RenderCfg)] + [_P] * 11

@@ -104,7 +104,7 @@ __device__ __forceinline__ void scatter_clear(float* M, int lane) {
 template <int VOFF, int VTOT>
 __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const float* Qs, const float (&vec)[VTOT],
                                               const float (&coef)[4], const int (&abs_off)[4], const int (&hs)[4],
-                                              float* M, int* tags, int i, int hi, int flags) {
+                                              float* M, int* tags, float* Ls, int i, int hi, int flags) {
     const bool no_global = (flags & TT_DBG_NO_GLOBAL_ATOMIC) != 0;
     // ---- claim slots and fill M: lane (i, hi) owns corners 2hi, 2hi+1 of sample i ----
     int lost = 0, wrote = 0, mine = 0;
@@ -158,15 +158,42 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
         if ((wrote >> q) & 1) M[hs[q] * MS + i] = 0.f;
         if ((mine >> q) & 1) tags[hs[q]] = -1;
     }
-    // ---- rare: references that lost their slot go straight to global memory ----
+    // ---- references that lost their slot (tile footprint wider than the 8x8 window: sparse rays) go straight to
+    // global memory, one half-wave per reference (lanes <-> channels: a coalesced 128-byte atomic each) ----
     if (__any(lost != 0) && !no_global) {
+        float* Lc = Ls;                                  // [sample][4] coefficient of a lost corner, else 0
+        int* Lo = reinterpret_cast<int*>(Ls + 32 * 4);   // [sample][4] absolute texel index
+        if (hi == 0) {
+            f32x4 c4;
+            i32x4 o4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if ((lost >> q) & 1) {
-                float* dst = grad + (size_t)abs_off[q] * TT_C + 4 * hi;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(dst + LIDX(r, 0), vec[VOFF + r] * coef[q]);
+            for (int q = 0; q < 4; ++q) {
+                c4[q] = ((lost >> q) & 1) ? coef[q] : 0.f;
+                o4[q] = abs_off[q];
             }
+            *reinterpret_cast<f32x4*>(Lc + 4 * i) = c4;
+            *reinterpret_cast<i32x4*>(Lo + 4 * i) = o4;
+        }
+        // walk only the samples that lost something, two per step (one per half-wave)
+        unsigned todo = (unsigned)(__ballot(lost != 0) & 0xffffffffull);
+        while (todo) {
+            const int s0 = __builtin_ctz(todo);
+            todo &= todo - 1;
+            int s1 = -1;
+            if (todo) {
+                s1 = __builtin_ctz(todo);
+                todo &= todo - 1;
+            }
+            const int sidx2 = hi ? s1 : s0;
+            if (sidx2 >= 0) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(Lc + 4 * sidx2);
+                const i32x4 o4 = *reinterpret_cast<const i32x4*>(Lo + 4 * sidx2);
+                const float v = Qs[sidx2 * 33 + i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c4[q] != 0.f) atomicAdd(grad + (size_t)o4[q] * TT_C + i, v * c4[q]);
+            }
+        }
     }
 }
 
@@ -193,6 +220,7 @@ struct BwdGeoParams {
     TileGeom geom;
     long long n_items;
     const float* ws;  // (n_rays*S, 4): d/d sdf, d/d sdf_grad xyz  (from k_march_bwd)
+    int n_copies;     // privatised copies of grad_packed
     float* grad_packed;
     MlpGradPtrs grads;
 };
@@ -219,6 +247,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     const size_t HW = (size_t)H * W;
     const size_t plane_stride = 6 * HW * TT_C;
     const float ju = 0.5f * W / cfg.radius, jv = 0.5f * H / cfg.radius;
+    // privatised gradient planes: this workgroup scatters into copy (blockIdx % n_copies); the copies are summed by
+    // tt_planes_unpack_grad.  Spreads same-texel atomics (which serialise at the memory side) over n_copies addresses.
+    float* const grad_out =
+        p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
 
     f32x16 accW1[2][1] = {{ZERO16}, {ZERO16}};
     f32x16 accW2[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};
@@ -229,8 +261,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         long long b;
         int ck;
         item_decode(ir, item, tg.order, tg.n_chunks, b, ck);
-        bool rvalid;
-        const long long ray = tile_ray(tg, b, i, rvalid);
+        bool ray_ok;
+        const long long ray = tile_ray(tg, b, i, ray_ok);
+        const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
         const int view = (int)(ray / cfg.rays_per_view);
         const size_t pofs = (size_t)(view / cfg.views_per_prompt) * plane_stride;
         const float* pbase = p.packed + pofs;
@@ -238,8 +271,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
         const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
 #pragma nounroll
-        for (int si = ck * tg.chunk; si < s_end; ++si) {
-            const long long sidx = ray * S + si;
+        for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb) {
+            const int si = sb0 + ks;
+            const bool rvalid = ray_ok && si < s_end;
+            const long long sidx = ray * S + (si < S ? si : S - 1);
             // upstream (from the march backward): d/d sdf and d/d sdf_grad of this sample
             f32x4 up = *reinterpret_cast<const f32x4*>(p.ws + sidx * 4);
             float sbar = rvalid ? up[0] : 0.f, gbx = rvalid ? up[1] : 0.f, gby = rvalid ? up[2] : 0.f,
@@ -320,8 +355,8 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4)
                             aoff[q4] = (int)(pofs / TT_C) + (int)(pl * HW) + cs[pl].off[q4];
-                        scatter_plane<0, 16>(p.grad_packed, Qs, q, coefs[pl], aoff, cs[pl].hs, Xs, tags, i, hi,
-                                             cfg.flags);
+                        scatter_plane<0, 16>(grad_out, Qs, q, coefs[pl], aoff, cs[pl].hs, Xs, tags, Qs + 32 * 33, i,
+                                             hi, cfg.flags);
                     }
                 }
             }
@@ -350,6 +385,7 @@ struct BwdTexParams {
     const float* g_features;
     TileGeom geom;
     long long n_items;
+    int n_copies;
     float* grad_packed;
     MlpGradPtrs grads;
 };
@@ -383,6 +419,8 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     const size_t plane_stride = 6 * HW * TT_C;
     const ItemRange ir = item_range(tg.n_blocks, tg.n_chunks);
     const float shrink = cfg.rgb_grad_shrink;
+    float* const grad_out =  // private copy of the gradient planes of this workgroup (see k_decode_bwd_geo)
+        p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
 
     f32x16 accV1a[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};  // dV1[:, 0:64]
     f32x16 accV1b[2][1] = {{ZERO16}, {ZERO16}};                  // dV1[:, 64:96]
@@ -394,9 +432,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
       long long b;
       int ck;
       item_decode(ir, item, tg.order, tg.n_chunks, b, ck);
-      bool rvalid;
-      const long long ray = tile_ray(tg, b, i, rvalid);
-      const bool valid = rvalid;
+      bool ray_ok;
+      const long long ray = tile_ray(tg, b, i, ray_ok);
+      const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
       const int view = (int)(ray / cfg.rays_per_view);
       const size_t pofs = (size_t)(view / cfg.views_per_prompt) * plane_stride;
       const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
@@ -406,8 +444,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
       for (int o = 0; o < 3; ++o) grgb[o] = p.g_rgb ? p.g_rgb[ray * 3 + o] : 0.f;
       const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
 #pragma nounroll
-      for (int si = ck * tg.chunk; si < s_end; ++si) {
-        const long long sidx = ray * S + si;
+      for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb) {
+        const int si = sb0 + ks;
+        const bool valid = ray_ok && si < s_end;
+        const long long sidx = ray * S + (si < S ? si : S - 1);
         // ---- upstream: cbar_o = shrink * w_i * g_rgb[ray,o] * 1.002 * s(1-s) + g_features ----
         float cb[3];
         {
@@ -498,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
                 float* Es = Ys;  // ebar staged as [sample][32], stride 33
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[r];
-                scatter_plane<0, 16>(p.grad_packed, Es, eb, c.w, aoff, c.hs, Xs, tags, i, hi, cfg.flags);
+                scatter_plane<0, 16>(grad_out, Es, eb, c.w, aoff, c.hs, Xs, tags, Es + 32 * 33, i, hi, cfg.flags);
             }
         }
       }
@@ -594,6 +634,7 @@ extern "C" int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, c
     p.cfg.flags |= debug_flags();
     p.ws = workspace;
     p.grad_packed = grad_packed;
+    p.n_copies = cfg->grad_copies > 0 ? cfg->grad_copies : 1;
     p.grads = to_gptrs(grads);
     p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom, 1);
     long long blocks = persistent_blocks(p.n_items, cus);
@@ -628,6 +669,7 @@ extern "C" int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, c
     p.g_rgb = g_rgb_fg;
     p.g_features = g_features;
     p.grad_packed = grad_packed;
+    p.n_copies = cfg->grad_copies > 0 ? cfg->grad_copies : 1;
     p.grads = to_gptrs(grads);
     p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom, 1);
     long long blocks = persistent_blocks(p.n_items, cus);

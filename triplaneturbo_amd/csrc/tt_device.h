@@ -391,11 +391,14 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
 }
 
 // ---- work decomposition of the per-sample kernels ----------------------------------------------------------
-// A TILE is 32 samples = 32 ADJACENT RAYS at the same sample index (an 8x4 pixel block when the image width is
-// known, else 32 consecutive rays): adjacent rays hit neighbouring texels at equal depth, so gathers hit L1 and
-// the plane-gradient scatter of a tile touches few distinct texels.  A WORK ITEM is (ray block, chunk of CH
-// consecutive sample indices); items are independent (the ray march is a separate kernel), so the grid is
-// balanced whatever the image size.  Block b runs on XCD b % 8 and every XCD owns one contiguous chunk of items
+// A TILE is 32 samples = RB ADJACENT RAYS x SB CONSECUTIVE SAMPLE INDICES (RB * SB = 32).  SB = 1 (uniform
+// sampling): an 8x4 pixel block at one sample index -- adjacent rays hit neighbouring texels at equal depth, so
+// gathers hit L1 and the plane-gradient scatter of a tile touches few distinct texels.  SB = 4 (importance
+// sampling: consecutive samples of a ray crowd into the same texels near the surface): a 4x2 pixel block x 4
+// consecutive samples, so those repeats are summed inside the tile instead of hammering one address with
+// atomics.  Without an image width the rays of a tile are RB consecutive rays.  A WORK ITEM is (ray block, chunk of
+// CH sample indices); items are independent (the ray march is a separate kernel), so the grid is balanced
+// whatever the image size.  Block b runs on XCD b % 8 and every XCD owns one contiguous chunk of items
 // (its texels stay in that XCD's L2).
 struct ItemRange {
     long long lo, hi;  // local item indices of this wave within its XCD's share: lo, lo+stride, ... < hi
@@ -434,25 +437,27 @@ __device__ __forceinline__ void item_decode(const ItemRange& g, long long li, in
 struct TileGeom {
     long long n_rays;
     int rays_per_view;
-    int image_w, image_h;  // image_w == 0: linear 32-ray strips
-    int bpr, bpv;          // 8x4 blocks per image row / per view
+    int image_w, image_h;  // image_w == 0: linear strips of RB rays
+    int sb, bw, bh;        // samples per ray per tile; pixel block bw x bh = 32 / sb rays
+    int bpr, bpv;          // pixel blocks per image row / per view
     int n_samples, chunk, n_chunks;
     long long n_blocks;
     int order;  // 0 chunk-major within an XCD, 1 block-major (TT_ORDER, tuning only)
 };
 
-// ray handled by lane j (0..31) of ray block b
+// ray handled by lane j (0..31) of ray block b; the lane's sample offset inside a tile step is j % sb
 __device__ __forceinline__ long long tile_ray(const TileGeom& g, long long b, int j, bool& rvalid) {
     long long ray;
+    const int jr = j / g.sb;
     if (g.image_w > 0) {
         const long long view = b / g.bpv;
         const int rem = (int)(b - view * g.bpv);
         const int by = rem / g.bpr, bx = rem - by * g.bpr;
-        const int x = bx * 8 + (j & 7), y = by * 4 + (j >> 3);
+        const int x = bx * g.bw + (jr % g.bw), y = by * g.bh + (jr / g.bw);
         rvalid = x < g.image_w && y < g.image_h;
         ray = view * g.rays_per_view + (long long)y * g.image_w + x;
     } else {
-        ray = b * 32 + j;
+        ray = b * (32 / g.sb) + jr;
         rvalid = true;
     }
     rvalid = rvalid && ray < g.n_rays;

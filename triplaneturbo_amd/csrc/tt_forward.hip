@@ -23,9 +23,10 @@ __device__ __forceinline__ void rot_dst(int k3, int y, int x, int H, int W, int&
     }
 }
 
+// UNPACK: src holds n_copies privatised copies (stride copy_stride floats) that are summed on the fly.
 template <bool UNPACK>
 __global__ __launch_bounds__(256) void k_planes_pack(const float* __restrict__ src, float* __restrict__ dst, int H,
-                                                     int W) {
+                                                     int W, int n_copies, size_t copy_stride) {
     extern __shared__ float tile[];  // [32][W+1]
     const int y = blockIdx.x, plane = blockIdx.y;  // plane = p*6 + k
     const int k3 = plane % 3;
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(256) void k_planes_pack(const float* __restrict__ s
         for (int e = threadIdx.x; e < TT_C * W; e += blockDim.x) {
             int x = e >> 5, c = e & 31, h, w;
             rot_dst(k3, y, x, H, W, h, w);
-            tile[c * ws + x] = nhwc[((size_t)h * W + w) * TT_C + c];
+            const size_t o = ((size_t)h * W + w) * TT_C + c;
+            float acc = nhwc[o];
+            for (int k = 1; k < n_copies; ++k) acc += nhwc[o + (size_t)k * copy_stride];
+            tile[c * ws + x] = acc;
         }
         __syncthreads();
         for (int e = threadIdx.x; e < TT_C * W; e += blockDim.x) {
@@ -334,8 +338,9 @@ __global__ __launch_bounds__(256, 2) void k_decode_rays(DecodeRaysParams p) {
         long long b;
         int ck;
         item_decode(ir, item, tg.order, tg.n_chunks, b, ck);
-        bool rvalid;
-        const long long ray = tile_ray(tg, b, i, rvalid);
+        bool ray_ok;
+        const long long ray = tile_ray(tg, b, i, ray_ok);
+        const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
         const int view = (int)(ray / cfg.rays_per_view);
         DecodeCfg dc;
         dc.pbase = p.packed + (size_t)(view / cfg.views_per_prompt) * plane_stride;
@@ -349,8 +354,10 @@ __global__ __launch_bounds__(256, 2) void k_decode_rays(DecodeRaysParams p) {
         const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
         const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
 #pragma nounroll
-        for (int si = ck * tg.chunk; si < s_end; ++si) {
-            const long long sidx = ray * S + si;
+        for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb) {
+            const int si = sb0 + ks;
+            const bool rvalid = ray_ok && si < s_end;
+            const long long sidx = ray * S + (si < S ? si : S - 1);
             const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
             float tm, px, py, pz;
             sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
@@ -396,18 +403,19 @@ extern "C" int tt_planes_pack(const float* space_cache, float* packed, int32_t n
     dim3 grid(plane_h, n_prompts * 6);
     size_t lds = (size_t)TT_C * (plane_w + 1) * sizeof(float);
     hipLaunchKernelGGL(k_planes_pack<false>, grid, dim3(256), lds, (hipStream_t)stream, space_cache, packed, plane_h,
-                       plane_w);
+                       plane_w, 1, (size_t)0);
     return tt_check_launch();
 }
 
 extern "C" int tt_planes_unpack_grad(const float* grad_packed, float* grad_space_cache, int32_t n_prompts,
-                                     int32_t plane_h, int32_t plane_w, void* stream) {
-    if (!grad_packed || !grad_space_cache || n_prompts <= 0 || plane_h <= 0 || plane_w <= 0) return TT_ERR_BAD_ARG;
+                                     int32_t plane_h, int32_t plane_w, int32_t n_copies, void* stream) {
+    if (!grad_packed || !grad_space_cache || n_prompts <= 0 || plane_h <= 0 || plane_w <= 0 || n_copies <= 0)
+        return TT_ERR_BAD_ARG;
     if (plane_h != plane_w) return TT_ERR_UNSUPPORTED;
     dim3 grid(plane_h, n_prompts * 6);
     size_t lds = (size_t)TT_C * (plane_w + 1) * sizeof(float);
     hipLaunchKernelGGL(k_planes_pack<true>, grid, dim3(256), lds, (hipStream_t)stream, grad_packed, grad_space_cache,
-                       plane_h, plane_w);
+                       plane_h, plane_w, n_copies, (size_t)n_prompts * 6 * plane_h * plane_w * TT_C);
     return tt_check_launch();
 }
 
@@ -473,24 +481,38 @@ long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom*
     g->image_w = 0;
     g->image_h = 0;
     g->bpr = g->bpv = 0;
+    int sb = cfg->tile_sb;
+    if (const char* e = getenv("TT_SB")) sb = atoi(e);  // tuning only
+    if (!(sb == 1 || sb == 2 || sb == 4 || sb == 8 || sb == 16 || sb == 32)) sb = 1;
+    while (sb > 1 && sb > cfg->n_samples) sb /= 2;
+    g->sb = sb;
+    static const int BW[6] = {8, 4, 4, 2, 2, 1}, BH[6] = {4, 4, 2, 2, 1, 1};
+    int l2 = 0;
+    while ((1 << l2) < sb) ++l2;
+    g->bw = BW[l2];
+    g->bh = BH[l2];
+    const int rb = 32 / sb;
     long long n_blocks;
     if (cfg->image_w > 0 && cfg->rays_per_view % cfg->image_w == 0) {
         g->image_w = cfg->image_w;
         g->image_h = cfg->rays_per_view / cfg->image_w;
-        g->bpr = (g->image_w + 7) / 8;
-        g->bpv = g->bpr * ((g->image_h + 3) / 4);
+        g->bpr = (g->image_w + g->bw - 1) / g->bw;
+        g->bpv = g->bpr * ((g->image_h + g->bh - 1) / g->bh);
         n_blocks = (cfg->n_rays / cfg->rays_per_view) * g->bpv;
     } else {
-        n_blocks = (cfg->n_rays + 31) / 32;
+        n_blocks = (cfg->n_rays + rb - 1) / rb;
     }
+    const int n_steps = (cfg->n_samples + sb - 1) / sb;
     int n_chunks = (int)((8 * wave_slots + n_blocks - 1) / n_blocks);
     if (n_chunks < 1) n_chunks = 1;
-    if (n_chunks > cfg->n_samples) n_chunks = cfg->n_samples;
+    if (n_chunks > n_steps) n_chunks = n_steps;
     if (const char* e = getenv("TT_CHUNK")) {  // tuning only
         int c = atoi(e);
         if (c > 0) n_chunks = (cfg->n_samples + c - 1) / c;
+        if (n_chunks > n_steps) n_chunks = n_steps;
     }
-    g->chunk = (cfg->n_samples + n_chunks - 1) / n_chunks;
+    const int steps_per_chunk = (n_steps + n_chunks - 1) / n_chunks;
+    g->chunk = steps_per_chunk * sb;  // always a multiple of sb
     g->n_chunks = (cfg->n_samples + g->chunk - 1) / g->chunk;
     g->n_blocks = n_blocks;
     g->order = default_order;

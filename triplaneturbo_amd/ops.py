@@ -97,6 +97,8 @@ class RenderConfig:
     inv_std: float = 100.0
     cos_anneal_ratio: float = 1.0
     rgb_grad_shrink: float = 1.0
+    tile_sb: int = 0  # consecutive samples of a ray per kernel tile (performance knob): 0/1 uniform, 4 importance
+    grad_copies: int = 1  # privatised copies of the plane-gradient buffer in the backward (performance knob)
 
 
 def planes_pack(space_cache: Tensor) -> Tensor:
@@ -111,10 +113,12 @@ def planes_pack(space_cache: Tensor) -> Tensor:
 
 
 def planes_unpack_grad(grad_packed: Tensor) -> Tensor:
+    """(P,6,H,W,32) or privatised (copies,P,6,H,W,32) packed gradients -> (P,6,32,H,W), copies summed."""
     grad_packed = _chk(grad_packed, "grad_packed")
-    P, _, H, W, _ = grad_packed.shape
+    copies = grad_packed.shape[0] if grad_packed.ndim == 6 else 1
+    P, _, H, W, _ = grad_packed.shape[-5:]
     out = torch.empty((P, 6, 32, H, W), device=grad_packed.device, dtype=torch.float32)
-    _lib.check(_lib.load().tt_planes_unpack_grad(_ptr(grad_packed), _ptr(out), P, H, W, _stream()),
+    _lib.check(_lib.load().tt_planes_unpack_grad(_ptr(grad_packed), _ptr(out), P, H, W, copies, _stream()),
                "tt_planes_unpack_grad")
     return out
 
@@ -168,7 +172,8 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
     return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
                           inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
                           _lib.TT_R_PER_SAMPLE if per_sample else 0,
-                          image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0)
+                          image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0, int(rc.tile_sb),
+                          max(1, int(rc.grad_copies)))
 
 
 def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
@@ -240,7 +245,8 @@ class _TriplaneRenderFn(torch.autograd.Function):
         cfg = _make_cfg(packed, n_rays, ctx.rays_per_view, S, ctx.rc, True, ctx.image_w)
         workspace = torch.empty((n_rays * S, 4), device=packed.device, dtype=torch.float32)
         wst, keep = _weights_struct((w1, w2, w3), (v1, v2, v3))
-        grad_packed = torch.zeros_like(packed)
+        copies = max(1, int(ctx.rc.grad_copies))
+        grad_packed = torch.zeros((copies,) + tuple(packed.shape), device=packed.device, dtype=torch.float32)
         gw = [torch.zeros_like(t) for t in (w1, w2, w3, v1, v2, v3)]
         gst = _grads_struct(gw)
 

@@ -162,6 +162,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         if text_embed is not None:
             assert text_embed.shape[0] == P
         assert B % P == 0, "batch of views must be a multiple of the number of prompts"
+        importance_sampled = t_starts is None
         if t_starts is None:
             t_starts, t_ends = self.sample(space_cache, rays_o, rays_d)
         if bg_color is None:
@@ -173,6 +174,8 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
             comp_rgb_bg = None
         sw, fw = self.geometry.mlp_weights()
         rc = self._render_config()
+        if importance_sampled:  # consecutive samples crowd into the same texels: 4x2-pixel x 4-sample tiles
+            rc.tile_sb = 4
         grad_on = self.training and torch.is_grad_enabled()
         ctx = torch.enable_grad() if grad_on else torch.no_grad()
         with ctx:
