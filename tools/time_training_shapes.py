@@ -1,0 +1,58 @@
+"""Dev tool: time one PatchRenderer forward+backward at the reference TRAINING shapes (2 prompts x 4 views, 42^2
+global + 40^2 patch rays, importance sampling 128 + 64 -> 193 samples, planes 256^2) with the per-entry-point
+breakdown (HIP events) next to the wall clock.     usage: python tools/time_training_shapes.py [steps]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import triplaneturbo_amd as tt  # noqa: E402
+from triplaneturbo_amd import ops, synthetic  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+g = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
+base = dict(estimator="importance", trainable_variance=False, learned_variance_init=0.4605, num_samples_per_ray=64,
+            num_samples_per_ray_importance=128, near_plane=0.1, far_plane=4.0, randomized=True)
+r = tt.find("patch-renderer")({"patch_size": 40, "global_downsample": 3,
+                               "base_renderer_type": "generative-space-sdf-volume-renderer", "base_renderer": base},
+                              geometry=g, material=tt.find("no-material")({}),
+                              background=tt.find("solid-color-background")({})).to(dev)
+r.train()
+gen = torch.Generator().manual_seed(1)
+cache = (torch.randn(2, 6, 32, 256, 256, generator=gen) * 0.5).to(dev).requires_grad_(True)
+ro, rd, c2w, cd = synthetic.make_cameras(8, 128, 128)
+kw = dict(space_cache=cache, text_embed=torch.zeros(2, 77, 1024), camera_distances=cd.to(dev), c2w=c2w.to(dev))
+ro, rd = ro.to(dev), rd.to(dev)
+bg = torch.ones(3, device=dev)
+
+
+def step():
+    out = r(ro, rd, None, bg, **kw)
+    loss = out["comp_rgb"].mean() + (out["opacity"] ** 2 + 0.01).sqrt().mean() + \
+        ((out["sdf_grad"].norm(dim=-1) - 1) ** 2).mean()
+    for p_ in [cache] + list(g.parameters()):
+        p_.grad = None
+    loss.backward()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    step()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / steps * 1e3
+t = ops.KernelTimer()
+ops.set_kernel_timer(t)
+for _ in range(steps):
+    step()
+torch.cuda.synchronize()
+ops.set_kernel_timer(None)
+per_step = {k: round(v[0] * v[1] / steps, 3) for k, v in t.summary().items()}  # avg ms x launches / steps
+print(f"training shapes: wall {wall:.2f} ms/step; HIP entry points (ms/step): {per_step} sum "
+      f"{sum(per_step.values()):.2f}", flush=True)

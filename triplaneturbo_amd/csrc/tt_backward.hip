@@ -219,6 +219,7 @@ struct BwdGeoParams {
     tt_render_cfg cfg;
     TileGeom geom;
     long long n_items;
+    int* queue;  // per-XCD item counters (tt_queue_counters)
     const float* ws;  // (n_rays*S, 4): d/d sdf, d/d sdf_grad xyz  (from k_march_bwd)
     int n_copies;     // privatised copies of grad_packed
     float* grad_packed;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     tags[lane] = -1;
     __syncthreads();
     const int S = cfg.n_samples;
-    const ItemRange ir = item_range(tg.n_blocks, tg.n_chunks);
+    ItemQueue iq = item_queue(p.queue, tg.n_blocks, tg.n_chunks, tg.unit);
     const int H = cfg.plane_h, W = cfg.plane_w;
     const size_t HW = (size_t)H * W;
     const size_t plane_stride = 6 * HW * TT_C;
@@ -257,10 +258,11 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     float accw3 = 0.f;
 
 #pragma nounroll
-    for (long long item = ir.lo; item < ir.hi; item += ir.stride) {
+    for (;;) {
         long long b;
         int ck;
-        item_decode(ir, item, tg.order, tg.n_chunks, b, ck);
+        if (!item_pop(iq, tg.order, tg.n_chunks, b, ck)) break;
+        if (b >= tg.n_blocks) continue;  // padding of the ragged last deal round
         bool ray_ok;
         const long long ray = tile_ray(tg, b, i, ray_ok);
         const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
@@ -385,6 +387,7 @@ struct BwdTexParams {
     const float* g_features;
     TileGeom geom;
     long long n_items;
+    int* queue;  // per-XCD item counters (tt_queue_counters)
     int n_copies;
     float* grad_packed;
     MlpGradPtrs grads;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     const int H = cfg.plane_h, W = cfg.plane_w;
     const size_t HW = (size_t)H * W;
     const size_t plane_stride = 6 * HW * TT_C;
-    const ItemRange ir = item_range(tg.n_blocks, tg.n_chunks);
+    ItemQueue iq = item_queue(p.queue, tg.n_blocks, tg.n_chunks, tg.unit);
     const float shrink = cfg.rgb_grad_shrink;
     float* const grad_out =  // private copy of the gradient planes of this workgroup (see k_decode_bwd_geo)
         p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
@@ -428,10 +431,11 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     float accV3[3] = {0.f, 0.f, 0.f};
 
 #pragma nounroll
-    for (long long item = ir.lo; item < ir.hi; item += ir.stride) {
+    for (;;) {
       long long b;
       int ck;
-      item_decode(ir, item, tg.order, tg.n_chunks, b, ck);
+      if (!item_pop(iq, tg.order, tg.n_chunks, b, ck)) break;
+        if (b >= tg.n_blocks) continue;  // padding of the ragged last deal round
       bool ray_ok;
       const long long ray = tile_ray(tg, b, i, ray_ok);
       const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
@@ -638,6 +642,9 @@ extern "C" int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, c
     p.grads = to_gptrs(grads);
     p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom, 1);
     long long blocks = persistent_blocks(p.n_items, cus);
+    if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
+    p.queue = tt_queue_counters(s);
+    if (!p.queue) return TT_ERR_DEVICE;
     hipLaunchKernelGGL(k_decode_bwd_geo, dim3((unsigned)blocks), dim3(256), 0, s, p);
     return tt_check_launch();
 }
@@ -673,6 +680,9 @@ extern "C" int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, c
     p.grads = to_gptrs(grads);
     p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom, 1);
     long long blocks = persistent_blocks(p.n_items, cus);
+    if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
+    p.queue = tt_queue_counters((hipStream_t)stream);
+    if (!p.queue) return TT_ERR_DEVICE;
     hipLaunchKernelGGL(k_decode_bwd_tex, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return tt_check_launch();
 }

@@ -398,40 +398,60 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
 // consecutive samples, so those repeats are summed inside the tile instead of hammering one address with
 // atomics.  Without an image width the rays of a tile are RB consecutive rays.  A WORK ITEM is (ray block, chunk of
 // CH sample indices); items are independent (the ray march is a separate kernel), so the grid is balanced
-// whatever the image size.  Block b runs on XCD b % 8 and every XCD owns one contiguous chunk of items
-// (its texels stay in that XCD's L2).
-struct ItemRange {
-    long long lo, hi;  // local item indices of this wave within its XCD's share: lo, lo+stride, ... < hi
-    int stride;
-    long long b_lo;    // first ray block of this XCD
-    long long nb;      // number of ray blocks of this XCD
+// whatever the image size.
+// ---- work distribution -------------------------------------------------------------------------------------
+// Ray blocks are dealt to the 8 XCDs round-robin in UNITS of consecutive blocks (unit u -> XCD u % 8, workgroup b
+// runs on XCD b % 8): every XCD sees the same mix of cheap (outside the volume: no gather, no scatter) and expensive
+// (through the object) image regions, and still works on compact groups of pixel blocks (its texels stay in its
+// 4 MB L2).  An XCD's items form a queue ordered chunk-major (local item li -> chunk li / nb, local block li % nb:
+// the waves running concurrently on an XCD work on neighbouring pixel blocks at the SAME depth range) or
+// block-major.  Waves POP items from their XCD's queue (one int32 atomic per item on a counter zeroed by the host
+// before the launch) and, once it is empty, steal from the other XCDs' queues: with static assignment the waves
+// were alive only ~75 % of the kernel (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES) because item cost varies ~3x and
+// items-per-wave does not divide evenly.
+struct ItemQueue {
+    int* ctr;          // [8] next local item per XCD
+    long long unit;    // blocks per deal unit
+    long long nb;      // local ray blocks per XCD (incl. the padding of a ragged last deal round)
+    long long n_local; // items per XCD queue = nb * n_chunks
+    int home;          // this workgroup's XCD
+    int hop;           // queues already found empty (0..8)
 };
-// Every XCD owns a contiguous range of RAY BLOCKS (all chunks of them).  Within the XCD, items are ordered
-// chunk-major: local item li -> chunk li / nb, block b_lo + li % nb, so the waves that run concurrently on one XCD
-// work on neighbouring pixel blocks at the SAME depth range -- a compact slab of space whose texels fit the XCD's
-// 4 MB L2 (block-major order had every XCD touch all depths at once: 42 % L2 hit rate).
-__device__ __forceinline__ ItemRange item_range(long long n_blocks, int n_chunks) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const long long per = (n_blocks + 7) / 8;
-    ItemRange g;
-    g.b_lo = xcd * per;
-    const long long b_hi = (g.b_lo + per < n_blocks) ? g.b_lo + per : n_blocks;
-    g.nb = b_hi > g.b_lo ? b_hi - g.b_lo : 0;
-    g.hi = g.nb * n_chunks;
-    g.stride = (gridDim.x >> 3) * (blockDim.x >> 6);
-    g.lo = slot * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    return g;
+__device__ __forceinline__ ItemQueue item_queue(int* ctr, long long n_blocks, int n_chunks, long long unit) {
+    ItemQueue q;
+    q.ctr = ctr;
+    q.unit = unit;
+    const long long n_units = (n_blocks + unit - 1) / unit;
+    q.nb = ((n_units + 7) / 8) * unit;
+    q.n_local = q.nb * n_chunks;
+    q.home = blockIdx.x & 7;
+    q.hop = 0;
+    return q;
 }
-__device__ __forceinline__ void item_decode(const ItemRange& g, long long li, int order, int n_chunks, long long& b,
-                                            int& ck) {
-    if (order == 0) {  // chunk-major (default)
-        ck = (int)(li / g.nb);
-        b = g.b_lo + (li - (long long)ck * g.nb);
-    } else {  // block-major
-        const long long bl = li / n_chunks;
-        ck = (int)(li - bl * n_chunks);
-        b = g.b_lo + bl;
+// next item for this wave: returns false when all queues are empty.  b may be >= n_blocks in the ragged last deal
+// round (caller skips it).  Wave-uniform.
+__device__ __forceinline__ bool item_pop(ItemQueue& q, int order, int n_chunks, long long& b, int& ck) {
+    while (q.hop < 8) {
+        const int xcd = (q.home + q.hop) & 7;
+        int li = 0;
+        if ((threadIdx.x & 63) == 0) li = atomicAdd(q.ctr + xcd, 1);
+        li = __builtin_amdgcn_readfirstlane(li);
+        if (li < q.n_local) {
+            long long bl;
+            if (order == 0) {  // chunk-major
+                ck = (int)(li / q.nb);
+                bl = li - (long long)ck * q.nb;
+            } else {  // block-major
+                bl = li / n_chunks;
+                ck = (int)(li - bl * n_chunks);
+            }
+            const long long round = bl / q.unit;
+            b = (round * 8 + xcd) * q.unit + (bl - round * q.unit);
+            return true;
+        }
+        ++q.hop;
     }
+    return false;
 }
 
 struct TileGeom {
@@ -442,6 +462,7 @@ struct TileGeom {
     int bpr, bpv;          // pixel blocks per image row / per view
     int n_samples, chunk, n_chunks;
     long long n_blocks;
+    long long unit;  // blocks per XCD deal unit (item_range)
     int order;  // 0 chunk-major within an XCD, 1 block-major (TT_ORDER, tuning only)
 };
 

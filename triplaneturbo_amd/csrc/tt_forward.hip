@@ -312,6 +312,7 @@ struct DecodeRaysParams {
     tt_render_cfg cfg;
     TileGeom geom;
     long long n_items;
+    int* queue;  // per-XCD item counters (tt_queue_counters)
     float* sdf;
     float* sdf_grad;
     float* features;
@@ -330,14 +331,15 @@ __global__ __launch_bounds__(256, 2) void k_decode_rays(DecodeRaysParams p) {
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const int S = cfg.n_samples;
-    const ItemRange ir = item_range(tg.n_blocks, tg.n_chunks);
+    ItemQueue iq = item_queue(p.queue, tg.n_blocks, tg.n_chunks, tg.unit);
     const size_t plane_stride = (size_t)6 * cfg.plane_h * cfg.plane_w * TT_C;
 
 #pragma nounroll
-    for (long long item = ir.lo; item < ir.hi; item += ir.stride) {
+    for (;;) {
         long long b;
         int ck;
-        item_decode(ir, item, tg.order, tg.n_chunks, b, ck);
+        if (!item_pop(iq, tg.order, tg.n_chunks, b, ck)) break;
+        if (b >= tg.n_blocks) continue;  // padding of the ragged last deal round
         bool ray_ok;
         const long long ray = tile_ray(tg, b, i, ray_ok);
         const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
@@ -503,7 +505,11 @@ long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom*
         n_blocks = (cfg->n_rays + rb - 1) / rb;
     }
     const int n_steps = (cfg->n_samples + sb - 1) / sb;
-    int n_chunks = (int)((8 * wave_slots + n_blocks - 1) / n_blocks);
+    // ~6 tile steps per item (measured sweet spot of the dynamic queue: per-item ray setup + one pop amortised,
+    // items fine enough that the last ones finish together), but at least 8 items per wave slot
+    int n_chunks = (n_steps + 5) / 6;
+    const int min_chunks = (int)((8 * wave_slots + n_blocks - 1) / n_blocks);
+    if (n_chunks < min_chunks) n_chunks = min_chunks;
     if (n_chunks < 1) n_chunks = 1;
     if (n_chunks > n_steps) n_chunks = n_steps;
     if (const char* e = getenv("TT_CHUNK")) {  // tuning only
@@ -515,6 +521,13 @@ long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom*
     g->chunk = steps_per_chunk * sb;  // always a multiple of sb
     g->n_chunks = (cfg->n_samples + g->chunk - 1) / g->chunk;
     g->n_blocks = n_blocks;
+    g->unit = n_blocks / 256;  // >= 32 deal rounds: ragged-round imbalance <= 3 %
+    if (g->unit > 32) g->unit = 32;
+    if (const char* e = getenv("TT_UNIT")) {  // tuning only
+        long long u = atoll(e);
+        if (u > 0) g->unit = u;
+    }
+    if (g->unit < 1) g->unit = 1;
     g->order = default_order;
     if (const char* e = getenv("TT_ORDER")) g->order = atoi(e) ? 1 : 0;  // tuning only
     return n_blocks * g->n_chunks;
@@ -550,12 +563,15 @@ extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const
     p.sdf_grad = sdf_grad;
     p.features = features;
     const long long slots = 2LL * cus * 4;  // 2 workgroups of 4 waves per CU (LDS 69 KB each)
-    p.n_items = tt_make_geom(cfg, slots, &p.geom, 0);
+    p.n_items = tt_make_geom(cfg, slots, &p.geom, 1);
     long long blocks = 2LL * cus;
     long long need = (p.n_items + 3) / 4;
     if (blocks > need) blocks = need;
     blocks = (blocks + 7) / 8 * 8;
     hipStream_t s = (hipStream_t)stream;
+    if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
+    p.queue = tt_queue_counters(s);
+    if (!p.queue) return TT_ERR_DEVICE;
     hipLaunchKernelGGL((k_decode_rays<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     st = tt_check_launch();
     if (st != TT_OK) return st;
@@ -590,13 +606,16 @@ extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, cons
     p.sdf_grad = sdf_grad;
     p.features = features;
     const long long slots = 2LL * cus * 4;
-    p.n_items = tt_make_geom(cfg, slots, &p.geom, 0);
+    p.n_items = tt_make_geom(cfg, slots, &p.geom, 1);
     long long blocks = 2LL * cus;
     long long need = (p.n_items + 3) / 4;
     if (blocks > need) blocks = need;
     blocks = (blocks + 7) / 8 * 8;
     dim3 grid((unsigned)blocks), blk(256);
     hipStream_t s = (hipStream_t)stream;
+    if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
+    p.queue = tt_queue_counters(s);
+    if (!p.queue) return TT_ERR_DEVICE;
     if (need_n && need_t)
         hipLaunchKernelGGL((k_decode_rays<true, true>), grid, blk, 0, s, p);
     else if (need_n)

@@ -1,7 +1,10 @@
-// tt_host.cpp -- status strings, launch checking, device queries (no global mutable state)
+// tt_host.cpp -- status strings, launch checking, device queries, the work-queue counter scratch
 #include "tt_host.h"
 
 #include <stdlib.h>
+
+#include <atomic>
+#include <mutex>
 
 extern "C" const char* tt_strerror(int status) {
     switch (status) {
@@ -23,4 +26,29 @@ int tt_num_cus() {
     if (hipGetDevice(&dev) != hipSuccess) return -1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
     return cus;
+}
+
+namespace {
+constexpr int kMaxDevices = 64, kSlots = 256, kSlotInts = 16;  // 64 B per slot: one cache line
+int* g_scratch[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+std::atomic<unsigned> g_next_slot{0};
+}  // namespace
+
+int* tt_queue_counters(hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    int* base;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch[dev]) {
+            void* ptr = nullptr;
+            if (hipMalloc(&ptr, (size_t)kSlots * kSlotInts * sizeof(int)) != hipSuccess) return nullptr;
+            g_scratch[dev] = static_cast<int*>(ptr);
+        }
+        base = g_scratch[dev];
+    }
+    int* slot = base + (size_t)(g_next_slot.fetch_add(1) % kSlots) * kSlotInts;
+    if (hipMemsetAsync(slot, 0, kSlotInts * sizeof(int), stream) != hipSuccess) return nullptr;
+    return slot;
 }

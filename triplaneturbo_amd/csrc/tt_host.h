@@ -10,6 +10,12 @@ int tt_validate_cfg(const tt_render_cfg* cfg);
 
 struct TileGeom;
 // fills the tile geometry / chunking for a render config; returns the number of work items.
-// default_order: 0 = chunk-major within an XCD (forward: best L2 reuse), 1 = block-major (backward: neighbouring
-// pixel blocks at the same depth would hammer the same texels with atomics at the same time).
+// default_order: order of an XCD's item queue, 0 = chunk-major, 1 = block-major (measured slightly faster in all
+// three kernels once the queue is dynamic: concurrent waves of an XCD then walk ONE pixel block's depth chunks and
+// its neighbours rather than one depth slab of the whole image share).
 long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g, int default_order);
+
+// Work-queue counters for one kernel launch: 8 zeroed int32 (one per XCD) in a library-owned device scratch of
+// 256 rotating slots per device; the zero-fill is enqueued on `stream` ahead of the launch.  Returns nullptr on a
+// HIP error.  (The only state the library keeps: a 16 KB allocation per device, never freed.)
+int* tt_queue_counters(hipStream_t stream);
