@@ -4,7 +4,8 @@
  * This is the drop-in boundary of triplaneturbo_amd.  Every entry point is plain C:
  * raw DEVICE pointers (fp32 unless noted), explicit sizes, a config struct, a hipStream_t
  * passed as void*.  The caller (PyTorch-ROCm host code, or any FFI) allocates every output
- * and workspace; nothing is allocated inside; no global state; re-entrant; safe from one
+ * and workspace; the library itself keeps one 16 KB device scratch per GPU (zeroed work-queue counters of the
+ * per-sample kernels, rotating slots, so launches on different streams do not share counters); re-entrant; safe from one
  * host thread per device.  Return 0 on success, a negative tt_status on error (no C++
  * exceptions cross the boundary).  tt_strerror() maps codes to text.
  *
@@ -25,6 +26,10 @@
  *                           generative_space_sdf_volume_renderer.py:326-431,467-472 (positions, geometry,
  *                           NoMaterial no_material.py:41-54, get_alpha neus_volume_renderer.py:93-117,
  *                           nerfacc.render_weight_from_alpha, nerfacc.accumulate_along_rays x5).
+ *   tt_march_fwd / _bwd     the ray march alone (second half of tt_render_fwd / first half of tt_render_bwd_geo):
+ *                           get_alpha neus_volume_renderer.py:93-117 + nerfacc.render_weight_from_alpha +
+ *                           nerfacc.accumulate_along_rays x5 (renderer :407-431,467-472) on given per-sample
+ *                           sdf / sdf_grad / features, and its backward.  Bandwidth-bound.
  *   tt_render_bwd_geo /     the autograd backward of the same, incl. the second-order terms the reference
  *   tt_render_bwd_tex       obtains from gridsample_cuda.cu:27-210 (grad2_2d, cuda_gridsample.py:68-79),
  *                           aten grid_sampler_2d_backward and the transposed cuBLAS GEMMs.
@@ -39,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 4
+#define TT_ABI_VERSION 5
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -146,6 +151,21 @@ int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const float* ray
                   const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, float* opacity, float* depth,
                   float* rgb_fg, float* z_variance, float* normal_acc, float* weights, float* trans, float* sdf,
                   float* sdf_grad, float* features, void* stream);
+
+/* The ray march alone, on per-sample sdf (n_rays*S), sdf_grad (.,3), features (.,3) that the caller already has
+ * (tt_decode_rays / tt_query_points): per-ray and per-sample outputs as in tt_render_fwd. */
+int tt_march_fwd(const float* rays_d, const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,
+                 const float* sdf, const float* sdf_grad, const float* features, float* opacity, float* depth,
+                 float* rgb_fg, float* z_variance, float* normal_acc, float* weights, float* trans, void* stream);
+
+/* Backward of tt_march_fwd down to the per-sample quantities: out_grad (n_rays*S,4) = (d/d sdf, d/d sdf_grad xyz),
+ * upstream grads as in tt_render_bwd_geo (null = 0).  (d/d features = weights * g_rgb_fg * d sigmoid is formed inside
+ * tt_render_bwd_tex.)  This is the `workspace` tt_render_bwd_geo fills for its decode backward. */
+int tt_march_bwd(const float* rays_d, const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,
+                 const float* opacity, const float* depth, const float* trans, const float* sdf,
+                 const float* sdf_grad, const float* features, const float* g_opacity, const float* g_depth,
+                 const float* g_rgb_fg, const float* g_z_variance, const float* g_normal_acc, const float* g_weights,
+                 const float* g_sdf, const float* g_sdf_grad, float* out_grad, void* stream);
 
 /* Backward, geometry half: d/d(geometry planes 0..2) and d/d(sdf net).
  * Per-ray upstream grads (any may be null = 0): g_opacity, g_depth, g_rgb_fg(3), g_z_variance, g_normal_acc(3).

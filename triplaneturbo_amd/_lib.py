@@ -22,6 +22,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomic
 SYMBOLS = [
     "tt_strerror", "tt_abi_version", "tt_planes_pack", "tt_planes_unpack_grad", "tt_query_points",
     "tt_query_field", "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2",
+    "tt_march_fwd", "tt_march_bwd",
 ]
 
 
@@ -108,6 +109,8 @@ def load() -> ctypes.CDLL:
     optional = {
         "tt_render_bwd_geo": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 14 + [_P, _P, _wp, _P],
         "tt_render_bwd_tex": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 4 + [_P, _wp, _P],
+        "tt_march_fwd": [_P, _P, _P, _cfgp] + [_P] * 11,
+        "tt_march_bwd": [_P, _P, _P, _cfgp] + [_P] * 16,
         "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
     }
     for name, argtypes in optional.items():

@@ -59,6 +59,76 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+struct FwdIn {
+    float ts, te, sdf, gx, gy, gz, f0, f1, f2;
+};
+__device__ __forceinline__ FwdIn march_load_fwd(const MarchFwdParams& p, long long sidx) {
+    FwdIn v;
+    v.ts = p.t_starts[sidx];
+    v.te = p.t_ends[sidx];
+    v.sdf = p.sdf[sidx];
+    v.gx = p.sdf_grad[sidx * 3 + 0];
+    v.gy = p.sdf_grad[sidx * 3 + 1];
+    v.gz = p.sdf_grad[sidx * 3 + 2];
+    v.f0 = p.features[sidx * 3 + 0];
+    v.f1 = p.features[sidx * 3 + 1];
+    v.f2 = p.features[sidx * 3 + 2];
+    return v;
+}
+struct FwdAcc {
+    float T, op, d, r, g, b, nx, ny, nz;
+};
+// one 64-sample pass of a ray: returns this lane's (weight, transmittance, t mid-point)
+__device__ __forceinline__ void march_pass_fwd(const MarchFwdParams& p, const FwdIn& v, bool valid, int lane, float dx,
+                                               float dy, float dz, FwdAcc& a, float& wgt, float& Ti, float& tm) {
+    tm = (v.ts + v.te) / 2.f;
+    const float gn = fmaxf(sqrtf(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz), 1e-12f);  // F.normalize eps
+    const float nx = v.gx / gn, ny = v.gy / gn, nz = v.gz / gn;
+    const float cosv = dx * nx + dy * ny + dz * nz;
+    float alpha = neus_alpha_terms(v.sdf, cosv, v.te - v.ts, p.inv_std, p.ratio).alpha;
+    if (!valid) alpha = 0.f;
+    float total;
+    Ti = a.T * seg_excl_prod<64>(1.f - alpha, lane, total);
+    a.T *= total;
+    wgt = alpha * Ti;
+    // NoMaterial + sigmoid-mipnerf (no_material.py:41-54, ops.py:118-119)
+    const float r = sigmoidf_(v.f0) * 1.002f - 0.001f, g = sigmoidf_(v.f1) * 1.002f - 0.001f,
+                b = sigmoidf_(v.f2) * 1.002f - 0.001f;
+    a.op += wgt;
+    a.d = fmaf(wgt, tm, a.d);
+    a.r = fmaf(wgt, r, a.r);
+    a.g = fmaf(wgt, g, a.g);
+    a.b = fmaf(wgt, b, a.b);
+    a.nx = fmaf(wgt, nx, a.nx);
+    a.ny = fmaf(wgt, ny, a.ny);
+    a.nz = fmaf(wgt, nz, a.nz);
+}
+__device__ __forceinline__ void march_reduce_fwd(FwdAcc& a) {
+    a.op = wave_sum(a.op);
+    a.d = wave_sum(a.d);
+    a.r = wave_sum(a.r);
+    a.g = wave_sum(a.g);
+    a.b = wave_sum(a.b);
+    a.nx = wave_sum(a.nx);
+    a.ny = wave_sum(a.ny);
+    a.nz = wave_sum(a.nz);
+}
+__device__ __forceinline__ void march_store_ray(const MarchFwdParams& p, long long ray, const FwdAcc& a, float zv) {
+    p.opacity[ray] = a.op;
+    p.depth[ray] = a.d;
+    p.rgb_fg[ray * 3 + 0] = a.r;
+    p.rgb_fg[ray * 3 + 1] = a.g;
+    p.rgb_fg[ray * 3 + 2] = a.b;
+    p.z_var[ray] = zv;
+    p.nacc[ray * 3 + 0] = a.nx;
+    p.nacc[ray * 3 + 1] = a.ny;
+    p.nacc[ray * 3 + 2] = a.nz;
+}
+
+// NP > 0: S <= 64 NP; all passes of the ray are loaded up front (every load of the ray in flight at once, no
+// dependent second round trip) and the lane's weights / mid-points stay in registers for z_variance.
+// NP == 0: any S, streaming (one pass in flight, z_variance re-reads the weights it just wrote).
+template <int NP>
 __global__ __launch_bounds__(256) void k_march_fwd(MarchFwdParams p) {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -66,70 +136,56 @@ __global__ __launch_bounds__(256) void k_march_fwd(MarchFwdParams p) {
     const int S = p.S;
     for (long long ray = wave; ray < p.n_rays; ray += n_waves) {
         const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
-        float T = 1.f;
-        float a_op = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f, a_nx = 0.f, a_ny = 0.f, a_nz = 0.f;
-        for (int base = 0; base < S; base += 64) {
-            const int si = base + lane;
-            const bool valid = si < S;
-            const long long sidx = ray * S + (valid ? si : 0);
-            const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
-            const float tm = (ts + te) / 2.f;
-            const float sdf = p.sdf[sidx];
-            const float gx = p.sdf_grad[sidx * 3 + 0], gy = p.sdf_grad[sidx * 3 + 1], gz = p.sdf_grad[sidx * 3 + 2];
-            const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps
-            const float nx = gx / gn, ny = gy / gn, nz = gz / gn;
-            const float cosv = dx * nx + dy * ny + dz * nz;
-            float alpha = neus_alpha_terms(sdf, cosv, te - ts, p.inv_std, p.ratio).alpha;
-            if (!valid) alpha = 0.f;
-            float total;
-            const float Ti = T * seg_excl_prod<64>(1.f - alpha, lane, total);
-            T *= total;
-            const float wgt = alpha * Ti;
-            // NoMaterial + sigmoid-mipnerf (no_material.py:41-54, ops.py:118-119)
-            const float r = sigmoidf_(p.features[sidx * 3 + 0]) * 1.002f - 0.001f,
-                        g = sigmoidf_(p.features[sidx * 3 + 1]) * 1.002f - 0.001f,
-                        b = sigmoidf_(p.features[sidx * 3 + 2]) * 1.002f - 0.001f;
-            a_op += wgt;
-            a_d = fmaf(wgt, tm, a_d);
-            a_r = fmaf(wgt, r, a_r);
-            a_g = fmaf(wgt, g, a_g);
-            a_b = fmaf(wgt, b, a_b);
-            a_nx = fmaf(wgt, nx, a_nx);
-            a_ny = fmaf(wgt, ny, a_ny);
-            a_nz = fmaf(wgt, nz, a_nz);
-            if (valid) {
-                p.weights[sidx] = wgt;
-                p.trans[sidx] = Ti;
+        FwdAcc a = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float zv = 0.f;
+        if constexpr (NP > 0) {
+            FwdIn in[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int si = 64 * k + lane;
+                in[k] = march_load_fwd(p, ray * S + (si < S ? si : 0));
+            }
+            float w[NP], tmid[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int si = 64 * k + lane;
+                float Ti;
+                march_pass_fwd(p, in[k], si < S, lane, dx, dy, dz, a, w[k], Ti, tmid[k]);
+                if (si < S) {
+                    p.weights[ray * S + si] = w[k];
+                    p.trans[ray * S + si] = Ti;
+                }
+            }
+            march_reduce_fwd(a);
+            // z_variance = sum w (t - depth)^2 (renderer :424-431)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const float dd = tmid[k] - a.d;
+                zv = fmaf(w[k], dd * dd, zv);  // w == 0 on padding lanes
+            }
+        } else {
+            for (int base = 0; base < S; base += 64) {
+                const int si = base + lane;
+                const bool valid = si < S;
+                const long long sidx = ray * S + (valid ? si : 0);
+                const FwdIn v = march_load_fwd(p, sidx);
+                float wgt, Ti, tm;
+                march_pass_fwd(p, v, valid, lane, dx, dy, dz, a, wgt, Ti, tm);
+                if (valid) {
+                    p.weights[sidx] = wgt;
+                    p.trans[sidx] = Ti;
+                }
+            }
+            march_reduce_fwd(a);
+            for (int si = lane; si < S; si += 64) {  // second pass over this lane's own weights
+                const long long sidx = ray * S + si;
+                const float tm = (p.t_starts[sidx] + p.t_ends[sidx]) / 2.f;
+                const float dd = tm - a.d;
+                zv = fmaf(p.weights[sidx], dd * dd, zv);
             }
         }
-        a_op = wave_sum(a_op);
-        a_d = wave_sum(a_d);
-        a_r = wave_sum(a_r);
-        a_g = wave_sum(a_g);
-        a_b = wave_sum(a_b);
-        a_nx = wave_sum(a_nx);
-        a_ny = wave_sum(a_ny);
-        a_nz = wave_sum(a_nz);
-        // z_variance = sum w (t - depth)^2 (renderer :424-431): second pass over this lane's own weights
-        float zv = 0.f;
-        for (int si = lane; si < S; si += 64) {
-            const long long sidx = ray * S + si;
-            const float tm = (p.t_starts[sidx] + p.t_ends[sidx]) / 2.f;
-            const float dd = tm - a_d;
-            zv = fmaf(p.weights[sidx], dd * dd, zv);
-        }
         zv = wave_sum(zv);
-        if (lane == 0) {
-            p.opacity[ray] = a_op;
-            p.depth[ray] = a_d;
-            p.rgb_fg[ray * 3 + 0] = a_r;
-            p.rgb_fg[ray * 3 + 1] = a_g;
-            p.rgb_fg[ray * 3 + 2] = a_b;
-            p.z_var[ray] = zv;
-            p.nacc[ray * 3 + 0] = a_nx;
-            p.nacc[ray * 3 + 1] = a_ny;
-            p.nacc[ray * 3 + 2] = a_nz;
-        }
+        if (lane == 0) march_store_ray(p, ray, a, zv);
     }
 }
 
@@ -157,86 +213,131 @@ struct MarchBwdParams {
     float* ws;  // (n_rays*S, 4): d/d sdf, d/d sdf_grad xyz
 };
 
+struct BwdIn {
+    float ts, te, sdf, gx, gy, gz, f0, f1, f2, trans, gw, gs, ggx, ggy, ggz;
+};
+__device__ __forceinline__ BwdIn march_load_bwd(const MarchBwdParams& p, long long sidx) {
+    BwdIn v;
+    v.ts = p.t_starts[sidx];
+    v.te = p.t_ends[sidx];
+    v.sdf = p.sdf[sidx];
+    v.gx = p.sdf_grad[sidx * 3 + 0];
+    v.gy = p.sdf_grad[sidx * 3 + 1];
+    v.gz = p.sdf_grad[sidx * 3 + 2];
+    v.f0 = p.features[sidx * 3 + 0];
+    v.f1 = p.features[sidx * 3 + 1];
+    v.f2 = p.features[sidx * 3 + 2];
+    v.trans = p.trans[sidx];
+    v.gw = p.g_weights ? p.g_weights[sidx] : 0.f;
+    v.gs = p.g_sdf ? p.g_sdf[sidx] : 0.f;
+    v.ggx = p.g_sdf_grad ? p.g_sdf_grad[sidx * 3 + 0] : 0.f;
+    v.ggy = p.g_sdf_grad ? p.g_sdf_grad[sidx * 3 + 1] : 0.f;
+    v.ggz = p.g_sdf_grad ? p.g_sdf_grad[sidx * 3 + 2] : 0.f;
+    return v;
+}
+struct RayBar {  // per-ray upstream gradients and forward results
+    float dx, dy, dz, op, D, b_op, b_d, b_z, b_r, b_g, b_b, b_nx, b_ny, b_nz;
+};
+// one 64-sample pass (passes run from the far end of the ray to the near end; Rcarry links them)
+__device__ __forceinline__ f32x4 march_pass_bwd(const MarchBwdParams& p, const BwdIn& v, bool valid, int lane,
+                                                const RayBar& rb, float& Rcarry) {
+    const float kstd = p.inv_std;
+    const float tm = (v.ts + v.te) / 2.f;
+    const float gn_raw = sqrtf(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz);
+    const float gn = fmaxf(gn_raw, 1e-12f);
+    const float nx = v.gx / gn, ny = v.gy / gn, nz = v.gz / gn;
+    const float cosv = rb.dx * nx + rb.dy * ny + rb.dz * nz;
+    const AlphaTerms a = neus_alpha_terms(v.sdf, cosv, v.te - v.ts, kstd, p.ratio);
+    const float alpha = valid ? a.alpha : 0.f;
+    const float Ti = valid ? v.trans : 0.f;
+    const float wgt = alpha * Ti;
+    const float rr = sigmoidf_(v.f0) * 1.002f - 0.001f, rg = sigmoidf_(v.f1) * 1.002f - 0.001f,
+                rbl = sigmoidf_(v.f2) * 1.002f - 0.001f;
+    // dL/dw_i (z_variance = sum w (t-D)^2 with D = sum w t)
+    const float dd = tm - rb.D;
+    float V = rb.b_op + rb.b_d * tm + rb.b_z * (dd * dd - 2.f * tm * rb.D * (1.f - rb.op)) +
+              (rb.b_r * rr + rb.b_g * rg + rb.b_b * rbl) + (rb.b_nx * nx + rb.b_ny * ny + rb.b_nz * nz);
+    V += v.gw;
+    if (!valid) V = 0.f;
+    // R_i = V_i a_i + (1 - a_i) R_{i+1};  dL/d alpha_i = T_i (V_i - R_{i+1})
+    const float Rnext = seg_rev_affine<64>(1.f - alpha, V * alpha, lane, Rcarry);
+    const float dalpha = Ti * (V - Rnext);
+    const float drat = (valid && a.pass) ? dalpha : 0.f;
+    const float dnum = drat / a.den, dden = -drat * a.rat / a.den;
+    const float dA = (dnum + dden) * a.sA * (1.f - a.sA) * kstd, dB = (-dnum) * a.sB * (1.f - a.sB) * kstd;
+    const float sbar = dA + dB;
+    const float dcos = a.half * (dB - dA) * a.dic_dcos;
+    const float nbx = wgt * rb.b_nx + dcos * rb.dx, nby = wgt * rb.b_ny + dcos * rb.dy,
+                nbz = wgt * rb.b_nz + dcos * rb.dz;
+    float gbx, gby, gbz;
+    if (gn_raw > 1e-12f) {
+        const float nd = nx * nbx + ny * nby + nz * nbz;
+        gbx = (nbx - nx * nd) / gn;
+        gby = (nby - ny * nd) / gn;
+        gbz = (nbz - nz * nd) / gn;
+    } else {
+        gbx = nbx / 1e-12f;
+        gby = nby / 1e-12f;
+        gbz = nbz / 1e-12f;
+    }
+    f32x4 o = {sbar + v.gs, gbx + v.ggx, gby + v.ggy, gbz + v.ggz};
+    return o;
+}
+
+// NP as in k_march_fwd: NP > 0 loads all passes of the ray before the (reverse) scans, NP == 0 streams.
+template <int NP>
 __global__ __launch_bounds__(256) void k_march_bwd(MarchBwdParams p) {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     const int S = p.S;
-    const float kstd = p.inv_std;
     for (long long ray = wave; ray < p.n_rays; ray += n_waves) {
-        const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
-        const float op = p.opacity[ray], D = p.depth[ray];
-        const float b_op = p.g_opacity ? p.g_opacity[ray] : 0.f;
-        const float b_d = p.g_depth ? p.g_depth[ray] : 0.f;
-        const float b_z = p.g_zvar ? p.g_zvar[ray] : 0.f;
-        const float b_r = p.g_rgb ? p.g_rgb[ray * 3 + 0] : 0.f, b_g = p.g_rgb ? p.g_rgb[ray * 3 + 1] : 0.f,
-                    b_b = p.g_rgb ? p.g_rgb[ray * 3 + 2] : 0.f;
-        const float b_nx = p.g_nacc ? p.g_nacc[ray * 3 + 0] : 0.f, b_ny = p.g_nacc ? p.g_nacc[ray * 3 + 1] : 0.f,
-                    b_nz = p.g_nacc ? p.g_nacc[ray * 3 + 2] : 0.f;
+        RayBar rb;
+        rb.dx = p.rays_d[ray * 3 + 0];
+        rb.dy = p.rays_d[ray * 3 + 1];
+        rb.dz = p.rays_d[ray * 3 + 2];
+        rb.op = p.opacity[ray];
+        rb.D = p.depth[ray];
+        rb.b_op = p.g_opacity ? p.g_opacity[ray] : 0.f;
+        rb.b_d = p.g_depth ? p.g_depth[ray] : 0.f;
+        rb.b_z = p.g_zvar ? p.g_zvar[ray] : 0.f;
+        rb.b_r = p.g_rgb ? p.g_rgb[ray * 3 + 0] : 0.f;
+        rb.b_g = p.g_rgb ? p.g_rgb[ray * 3 + 1] : 0.f;
+        rb.b_b = p.g_rgb ? p.g_rgb[ray * 3 + 2] : 0.f;
+        rb.b_nx = p.g_nacc ? p.g_nacc[ray * 3 + 0] : 0.f;
+        rb.b_ny = p.g_nacc ? p.g_nacc[ray * 3 + 1] : 0.f;
+        rb.b_nz = p.g_nacc ? p.g_nacc[ray * 3 + 2] : 0.f;
         float Rcarry = 0.f;
-        for (int base = ((S - 1) / 64) * 64; base >= 0; base -= 64) {
-            const int si = base + lane;
-            const bool valid = si < S;
-            const long long sidx = ray * S + (valid ? si : 0);
-            const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
-            const float tm = (ts + te) / 2.f;
-            const float sdf = p.sdf[sidx];
-            const float gx = p.sdf_grad[sidx * 3 + 0], gy = p.sdf_grad[sidx * 3 + 1], gz = p.sdf_grad[sidx * 3 + 2];
-            const float gn_raw = sqrtf(gx * gx + gy * gy + gz * gz);
-            const float gn = fmaxf(gn_raw, 1e-12f);
-            const float nx = gx / gn, ny = gy / gn, nz = gz / gn;
-            const float cosv = dx * nx + dy * ny + dz * nz;
-            const AlphaTerms a = neus_alpha_terms(sdf, cosv, te - ts, kstd, p.ratio);
-            const float alpha = valid ? a.alpha : 0.f;
-            const float Ti = valid ? p.trans[sidx] : 0.f;
-            const float wgt = alpha * Ti;
-            const float rr = sigmoidf_(p.features[sidx * 3 + 0]) * 1.002f - 0.001f,
-                        rg = sigmoidf_(p.features[sidx * 3 + 1]) * 1.002f - 0.001f,
-                        rb = sigmoidf_(p.features[sidx * 3 + 2]) * 1.002f - 0.001f;
-            // dL/dw_i (z_variance = sum w (t-D)^2 with D = sum w t)
-            const float dd = tm - D;
-            float V = b_op + b_d * tm + b_z * (dd * dd - 2.f * tm * D * (1.f - op)) + (b_r * rr + b_g * rg + b_b * rb) +
-                      (b_nx * nx + b_ny * ny + b_nz * nz);
-            if (p.g_weights) V += p.g_weights[sidx];
-            if (!valid) V = 0.f;
-            // R_i = V_i a_i + (1 - a_i) R_{i+1};  dL/d alpha_i = T_i (V_i - R_{i+1})
-            const float Rnext = seg_rev_affine<64>(1.f - alpha, V * alpha, lane, Rcarry);
-            const float dalpha = Ti * (V - Rnext);
-            const float drat = (valid && a.pass) ? dalpha : 0.f;
-            const float dnum = drat / a.den, dden = -drat * a.rat / a.den;
-            const float dA = (dnum + dden) * a.sA * (1.f - a.sA) * kstd, dB = (-dnum) * a.sB * (1.f - a.sB) * kstd;
-            float sbar = dA + dB;
-            const float dcos = a.half * (dB - dA) * a.dic_dcos;
-            const float nbx = wgt * b_nx + dcos * dx, nby = wgt * b_ny + dcos * dy, nbz = wgt * b_nz + dcos * dz;
-            float gbx, gby, gbz;
-            if (gn_raw > 1e-12f) {
-                const float nd = nx * nbx + ny * nby + nz * nbz;
-                gbx = (nbx - nx * nd) / gn;
-                gby = (nby - ny * nd) / gn;
-                gbz = (nbz - nz * nd) / gn;
-            } else {
-                gbx = nbx / 1e-12f;
-                gby = nby / 1e-12f;
-                gbz = nbz / 1e-12f;
+        if constexpr (NP > 0) {
+            BwdIn in[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int si = 64 * k + lane;
+                in[k] = march_load_bwd(p, ray * S + (si < S ? si : 0));
             }
-            if (valid) {
-                if (p.g_sdf) sbar += p.g_sdf[sidx];
-                if (p.g_sdf_grad) {
-                    gbx += p.g_sdf_grad[sidx * 3 + 0];
-                    gby += p.g_sdf_grad[sidx * 3 + 1];
-                    gbz += p.g_sdf_grad[sidx * 3 + 2];
-                }
-                f32x4 o = {sbar, gbx, gby, gbz};
-                *reinterpret_cast<f32x4*>(p.ws + sidx * 4) = o;
+#pragma unroll
+            for (int k = NP - 1; k >= 0; --k) {
+                const int si = 64 * k + lane;
+                const f32x4 o = march_pass_bwd(p, in[k], si < S, lane, rb, Rcarry);
+                if (si < S) *reinterpret_cast<f32x4*>(p.ws + (ray * S + si) * 4) = o;
+            }
+        } else {
+            for (int base = ((S - 1) / 64) * 64; base >= 0; base -= 64) {
+                const int si = base + lane;
+                const bool valid = si < S;
+                const long long sidx = ray * S + (valid ? si : 0);
+                const BwdIn v = march_load_bwd(p, sidx);
+                const f32x4 o = march_pass_bwd(p, v, valid, lane, rb, Rcarry);
+                if (valid) *reinterpret_cast<f32x4*>(p.ws + sidx * 4) = o;
             }
         }
     }
 }
 
+// one ray per wave (the dispatcher overlaps the load phase of fresh waves with the scans of resident ones)
 static unsigned march_blocks(long long n_rays) {
-    int cus = tt_num_cus();
     long long blocks = (n_rays + 3) / 4;
-    long long cap = (long long)(cus > 0 ? cus : 256) * 8;
+    const long long cap = 1LL << 22;
     if (blocks > cap) blocks = cap;
     return (unsigned)(blocks < 1 ? 1 : blocks);
 }
@@ -263,7 +364,15 @@ int tt_launch_march_fwd(const float* rays_d, const float* t_starts, const float*
     p.nacc = normal_acc;
     p.weights = weights;
     p.trans = trans;
-    hipLaunchKernelGGL(k_march_fwd, dim3(march_blocks(cfg->n_rays)), dim3(256), 0, stream, p);
+    const dim3 grid(march_blocks(cfg->n_rays)), blk(256);
+    if (p.S <= 64)
+        hipLaunchKernelGGL(k_march_fwd<1>, grid, blk, 0, stream, p);
+    else if (p.S <= 128)
+        hipLaunchKernelGGL(k_march_fwd<2>, grid, blk, 0, stream, p);
+    else if (p.S <= 256)
+        hipLaunchKernelGGL(k_march_fwd<4>, grid, blk, 0, stream, p);
+    else
+        hipLaunchKernelGGL(k_march_fwd<0>, grid, blk, 0, stream, p);
     return tt_check_launch();
 }
 
@@ -296,6 +405,42 @@ int tt_launch_march_bwd(const float* rays_d, const float* t_starts, const float*
     p.inv_std = cfg->inv_std;
     p.ratio = cfg->cos_anneal_ratio;
     p.ws = ws;
-    hipLaunchKernelGGL(k_march_bwd, dim3(march_blocks(cfg->n_rays)), dim3(256), 0, stream, p);
+    const dim3 grid(march_blocks(cfg->n_rays)), blk(256);
+    if (p.S <= 64)
+        hipLaunchKernelGGL(k_march_bwd<1>, grid, blk, 0, stream, p);
+    else if (p.S <= 128)
+        hipLaunchKernelGGL(k_march_bwd<2>, grid, blk, 0, stream, p);
+    else if (p.S <= 256)
+        hipLaunchKernelGGL(k_march_bwd<4>, grid, blk, 0, stream, p);
+    else
+        hipLaunchKernelGGL(k_march_bwd<0>, grid, blk, 0, stream, p);
     return tt_check_launch();
+}
+
+extern "C" int tt_march_fwd(const float* rays_d, const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,
+                            const float* sdf, const float* sdf_grad, const float* features, float* opacity,
+                            float* depth, float* rgb_fg, float* z_variance, float* normal_acc, float* weights,
+                            float* trans, void* stream) {
+    int st = tt_validate_cfg(cfg);
+    if (st != TT_OK) return st;
+    if (!rays_d || !t_starts || !t_ends || !sdf || !sdf_grad || !features || !opacity || !depth || !rgb_fg ||
+        !z_variance || !normal_acc || !weights || !trans)
+        return TT_ERR_BAD_ARG;
+    return tt_launch_march_fwd(rays_d, t_starts, t_ends, cfg, sdf, sdf_grad, features, opacity, depth, rgb_fg,
+                               z_variance, normal_acc, weights, trans, (hipStream_t)stream);
+}
+
+extern "C" int tt_march_bwd(const float* rays_d, const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,
+                            const float* opacity, const float* depth, const float* trans, const float* sdf,
+                            const float* sdf_grad, const float* features, const float* g_opacity,
+                            const float* g_depth, const float* g_rgb_fg, const float* g_z_variance,
+                            const float* g_normal_acc, const float* g_weights, const float* g_sdf,
+                            const float* g_sdf_grad, float* out_grad, void* stream) {
+    int st = tt_validate_cfg(cfg);
+    if (st != TT_OK) return st;
+    if (!rays_d || !t_starts || !t_ends || !opacity || !depth || !trans || !sdf || !sdf_grad || !features || !out_grad)
+        return TT_ERR_BAD_ARG;
+    return tt_launch_march_bwd(rays_d, t_starts, t_ends, cfg, sdf, sdf_grad, features, trans, opacity, depth,
+                               g_opacity, g_depth, g_rgb_fg, g_z_variance, g_normal_acc, g_weights, g_sdf, g_sdf_grad,
+                               out_grad, (hipStream_t)stream);
 }

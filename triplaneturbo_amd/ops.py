@@ -210,6 +210,60 @@ def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
     return out
 
 
+@torch.no_grad()
+def march_forward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, sdf: Tensor, sdf_grad: Tensor,
+                      features: Tensor, rc: RenderConfig, out: Optional[dict] = None):
+    """The ray march alone (tt_march_fwd): NeuS alpha, transmittance, weights and the five accumulations, on
+    per-sample sdf (n_rays*S,1), sdf_grad (.,3), features (.,3) already decoded.  No grad (the differentiable path is
+    render_samples).  `out` may hold preallocated result tensors (bench: re-time the march on live buffers)."""
+    rays_d, t_starts, t_ends = _chk(rays_d, "rays_d"), _chk(t_starts, "t_starts"), _chk(t_ends, "t_ends")
+    sdf, sdf_grad, features = _chk(sdf, "sdf"), _chk(sdf_grad, "sdf_grad"), _chk(features, "features")
+    n_rays, S = t_starts.shape
+    if sdf.numel() != n_rays * S or sdf_grad.numel() != 3 * n_rays * S or features.numel() != 3 * n_rays * S:
+        raise ValueError("per-sample tensors do not match (n_rays, S)")
+    cfg = _lib.RenderCfg(n_prompts=1, views_per_prompt=1, plane_h=1, plane_w=1, rays_per_view=n_rays, n_samples=S,
+                         n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=rc.inv_std,
+                         cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink, flags=0, image_w=0,
+                         tile_sb=0, grad_copies=1)
+    f32 = dict(device=rays_d.device, dtype=torch.float32)
+    if out is None:
+        out = {"opacity": torch.empty((n_rays, 1), **f32), "depth": torch.empty((n_rays, 1), **f32),
+               "rgb_fg": torch.empty((n_rays, 3), **f32), "z_variance": torch.empty((n_rays, 1), **f32),
+               "normal_acc": torch.empty((n_rays, 3), **f32), "weights": torch.empty((n_rays * S, 1), **f32),
+               "trans": torch.empty((n_rays * S, 1), **f32)}
+    with _timed("tt_march_fwd"):
+        st = _lib.load().tt_march_fwd(_ptr(rays_d), _ptr(t_starts), _ptr(t_ends), ctypes.byref(cfg), _ptr(sdf),
+                                      _ptr(sdf_grad), _ptr(features), _ptr(out["opacity"]), _ptr(out["depth"]),
+                                      _ptr(out["rgb_fg"]), _ptr(out["z_variance"]), _ptr(out["normal_acc"]),
+                                      _ptr(out["weights"]), _ptr(out["trans"]), _stream())
+    _lib.check(st, "tt_march_fwd")
+    return out
+
+
+@torch.no_grad()
+def march_backward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, fwd: dict, sdf: Tensor, sdf_grad: Tensor,
+                       features: Tensor, rc: RenderConfig, g_opacity=None, g_depth=None, g_rgb_fg=None,
+                       g_z_variance=None, g_normal_acc=None, g_weights=None, g_sdf=None, g_sdf_grad=None,
+                       out: Optional[Tensor] = None):
+    """tt_march_bwd: (n_rays*S, 4) = (d/d sdf, d/d sdf_grad) from upstream gradients of the march outputs; `fwd` is
+    the dict march_forward_raw / render_forward_raw returned (opacity, depth, trans)."""
+    n_rays, S = t_starts.shape
+    cfg = _lib.RenderCfg(n_prompts=1, views_per_prompt=1, plane_h=1, plane_w=1, rays_per_view=n_rays, n_samples=S,
+                         n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=rc.inv_std,
+                         cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink, flags=0, image_w=0,
+                         tile_sb=0, grad_copies=1)
+    if out is None:
+        out = torch.empty((n_rays * S, 4), device=rays_d.device, dtype=torch.float32)
+    c = lambda t: None if t is None else t.contiguous()
+    gs = [c(t) for t in (g_opacity, g_depth, g_rgb_fg, g_z_variance, g_normal_acc, g_weights, g_sdf, g_sdf_grad)]
+    with _timed("tt_march_bwd"):
+        st = _lib.load().tt_march_bwd(_ptr(rays_d), _ptr(t_starts), _ptr(t_ends), ctypes.byref(cfg),
+                                      _ptr(fwd["opacity"]), _ptr(fwd["depth"]), _ptr(fwd["trans"]), _ptr(sdf),
+                                      _ptr(sdf_grad), _ptr(features), *[_ptr(t) for t in gs], _ptr(out), _stream())
+    _lib.check(st, "tt_march_bwd")
+    return out
+
+
 def _grads_struct(tensors: Sequence[Tensor]):
     return _lib.MlpWeights(*[_ptr(t) for t in tensors])  # same layout as tt_mlp_grads (6 pointers)
 
