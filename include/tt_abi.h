@@ -22,6 +22,11 @@
  *                           and forward_sdf :353-373 (flags without TT_Q_TEX / TT_Q_NORMAL).
  *   tt_query_field          forward_field :375-394 (sdf + deformation head; mesh renderer / exporter grid query)
  *   tt_decode_rays          the geometry call of prop_sigma_fn (renderer :243-299 -> few_step...:273-306, sdf only)
+ *   tt_sample_uniform       ImportanceEstimator.sampling level 0 (threestudio/models/estimators.py:61-79 with
+ *                           _transform_stot "uniform" :104-118): n equal / stratified intervals on [near, far].
+ *   tt_sample_importance    the rest of ImportanceEstimator.sampling (estimators.py:72-101) with prop_sigma_fn's
+ *                           fixed-step NeuS density (renderer :288-297): nerfacc render_transmittance_from_density,
+ *                           importance_sampling (inverse-CDF resample) and the merge + sort of the edges (:317-324).
  *   tt_render_fwd           GenerativeSpaceSDFVolumeRenderer._forward
  *                           generative_space_sdf_volume_renderer.py:326-431,467-472 (positions, geometry,
  *                           NoMaterial no_material.py:41-54, get_alpha neus_volume_renderer.py:93-117,
@@ -44,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 5
+#define TT_ABI_VERSION 6
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -139,6 +144,20 @@ int tt_query_field(const float* packed, const tt_mlp_weights* w, const float* po
 int tt_decode_rays(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
                    const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, int32_t flags, float* sdf,
                    float* sdf_grad, float* features, void* stream);
+
+/* Level-0 sample intervals: edges s_k = linspace(0,1,n+1)[k] (+ (jitter-0.5)/n on interior edges if jitter
+ * (n_rays, n+1), U[0,1), is given), t = s*far + (1-s)*near; t_starts/t_ends (n_rays, n). */
+int tt_sample_uniform(int64_t n_rays, int32_t n_samples, float near_plane, float far_plane, const float* jitter,
+                      float* t_starts, float* t_ends, void* stream);
+
+/* Importance resampling of one proposal level.  In: proposal intervals t_starts/t_ends (n_rays, K) and the sdf
+ * (n_rays, K) at their mid-points (tt_decode_rays, flags = 0).  sigma = NeuS alpha over a fixed step / step,
+ * T = exp(-exclusive_cumsum(sigma dt)), cdf = 1 - [T, 0]; F + 1 fine edges at u_j = j/F (+ u_jitter/F, clamped, if
+ * u_jitter (n_rays, F+1) is given) through the piecewise-linear inverse cdf; out = the K + F + 2 edges merged in
+ * increasing order as out_t_starts/out_t_ends (n_rays, K + F + 1). */
+int tt_sample_importance(const float* t_starts, const float* t_ends, const float* sdf, int64_t n_rays,
+                         int32_t n_proposal, int32_t n_fine, float inv_std, float render_step_size,
+                         const float* u_jitter, float* out_t_starts, float* out_t_ends, void* stream);
 
 /* Forward render for explicit sample intervals.
  * rays_o, rays_d (n_rays,3); t_starts, t_ends (n_rays,S).

@@ -15,14 +15,14 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libtt_hip.so")
-SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_grad2.hip", "tt_host.cpp"]
+SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_host.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared", "-fno-gpu-rdc"]
 
 # every symbol include/tt_abi.h declares (tests check the header and this list agree)
 SYMBOLS = [
     "tt_strerror", "tt_abi_version", "tt_planes_pack", "tt_planes_unpack_grad", "tt_query_points",
     "tt_query_field", "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2",
-    "tt_march_fwd", "tt_march_bwd",
+    "tt_march_fwd", "tt_march_bwd", "tt_sample_uniform", "tt_sample_importance",
 ]
 
 
@@ -111,6 +111,8 @@ def load() -> ctypes.CDLL:
         "tt_render_bwd_tex": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 4 + [_P, _wp, _P],
         "tt_march_fwd": [_P, _P, _P, _cfgp] + [_P] * 11,
         "tt_march_bwd": [_P, _P, _P, _cfgp] + [_P] * 16,
+        "tt_sample_uniform": [_I64, _I32, _F, _F, _P, _P, _P, _P],
+        "tt_sample_importance": [_P, _P, _P, _I64, _I32, _I32, _F, _F, _P, _P, _P, _P],
         "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
     }
     for name, argtypes in optional.items():

@@ -211,6 +211,49 @@ def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
 
 
 @torch.no_grad()
+def sample_uniform(n_rays: int, n_samples: int, near: float, far: float, device, jitter: Optional[Tensor] = None):
+    """tt_sample_uniform: level-0 intervals (n_rays, n_samples); jitter (n_rays, n_samples+1) U[0,1) => stratified."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("triplaneturbo_amd samplers run on the GPU only (no CPU fallback)")
+    f32 = dict(device=device, dtype=torch.float32)
+    ts, te = torch.empty((n_rays, n_samples), **f32), torch.empty((n_rays, n_samples), **f32)
+    if jitter is not None:
+        jitter = _chk(jitter, "jitter")
+        if jitter.shape != (n_rays, n_samples + 1):
+            raise ValueError("jitter must be (n_rays, n_samples + 1)")
+    with torch.cuda.device(device):
+        st = _lib.load().tt_sample_uniform(n_rays, n_samples, float(near), float(far), _ptr(jitter), _ptr(ts),
+                                           _ptr(te), _stream())
+    _lib.check(st, "tt_sample_uniform")
+    return ts, te
+
+
+@torch.no_grad()
+def sample_importance(t_starts: Tensor, t_ends: Tensor, sdf: Tensor, n_fine: int, inv_std: float,
+                      render_step_size: float, u_jitter: Optional[Tensor] = None):
+    """tt_sample_importance: proposal intervals (n_rays, K) + sdf at their mid-points -> (n_rays, K + n_fine + 1)
+    intervals (proposal edges merged with n_fine + 1 inverse-CDF edges)."""
+    t_starts, t_ends, sdf = _chk(t_starts, "t_starts"), _chk(t_ends, "t_ends"), _chk(sdf, "sdf")
+    n_rays, K = t_starts.shape
+    if t_ends.shape != (n_rays, K) or sdf.numel() != n_rays * K:
+        raise ValueError("proposal intervals / sdf shapes disagree")
+    if u_jitter is not None:
+        u_jitter = _chk(u_jitter, "u_jitter")
+        if u_jitter.shape != (n_rays, n_fine + 1):
+            raise ValueError("u_jitter must be (n_rays, n_fine + 1)")
+    f32 = dict(device=t_starts.device, dtype=torch.float32)
+    M = K + n_fine + 1
+    ots, ote = torch.empty((n_rays, M), **f32), torch.empty((n_rays, M), **f32)
+    with _timed("tt_sample_importance"):
+        st = _lib.load().tt_sample_importance(_ptr(t_starts), _ptr(t_ends), _ptr(sdf), n_rays, K, int(n_fine),
+                                              float(inv_std), float(render_step_size), _ptr(u_jitter), _ptr(ots),
+                                              _ptr(ote), _stream())
+    _lib.check(st, "tt_sample_importance")
+    return ots, ote
+
+
+@torch.no_grad()
 def march_forward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, sdf: Tensor, sdf_grad: Tensor,
                       features: Tensor, rc: RenderConfig, out: Optional[dict] = None):
     """The ray march alone (tt_march_fwd): NeuS alpha, transmittance, weights and the five accumulations, on
