@@ -38,6 +38,9 @@
  *   tt_render_bwd_geo /     the autograd backward of the same, incl. the second-order terms the reference
  *   tt_render_bwd_tex       obtains from gridsample_cuda.cu:27-210 (grad2_2d, cuda_gridsample.py:68-79),
  *                           aten grid_sampler_2d_backward and the transposed cuBLAS GEMMs.
+ *   tt_points_bwd_geo /     the autograd backward of tt_query_points / tt_query_field w.r.t. planes and MLP weights
+ *   tt_points_bwd_tex       (training-time callers: generative_space_mesh_rasterize_renderer.py:428-452 field
+ *                           query, :321-376 per-pixel geometry decode); same kernels as tt_render_bwd_*.
  *   tt_grid_sample_2d_grad2 gridsample_cuda.cpp:26-37 `grad2_2d` itself (operator-level drop-in).
  */
 #ifndef TT_ABI_H
@@ -49,7 +52,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 6
+#define TT_ABI_VERSION 7
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -205,6 +208,23 @@ int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, const float*
 int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
                       const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, const float* weights,
                       const float* features, const float* g_rgb_fg, const float* g_features, float* grad_packed,
+                      const tt_mlp_grads* grads, void* stream);
+
+/* Backward of the per-point queries.  points (n_batch, n_points, 3) as in tt_query_points (constants: no
+ * gradient w.r.t. the points is produced).
+ * _geo: upstream g_sdf (n) and/or g_sdf_grad (n,3) (one may be null) -> d/d geometry planes 0..2 (accumulated into
+ *       grad_packed, caller zero-fills) and d/d sdf net (grads->w1..w3).  workspace: n*4 floats.
+ * _tex: upstream g_features (n,3) of a 96->64->64->3 net in w->v1..v3 reading planes plane_base..plane_base+2 of
+ *       each prompt: plane_base = 3 is the feature net on the texture planes (tt_query_points with TT_Q_TEX);
+ *       plane_base = 0 with v1 = [U1 U1 U1] is a 32->64->64->3 net on the SUM of the geometry planes, i.e. the
+ *       deformation head of tt_query_field (d/d U1 = the sum of the three 64x32 column blocks of grads->v1). */
+int tt_points_bwd_geo(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
+                      int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
+                      float radius, float sdf_bias_radius, const float* g_sdf, const float* g_sdf_grad,
+                      float* workspace, float* grad_packed, const tt_mlp_grads* grads, void* stream);
+int tt_points_bwd_tex(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
+                      int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
+                      float radius, int32_t plane_base, const float* g_features, float* grad_packed,
                       const tt_mlp_grads* grads, void* stream);
 
 /* Operator-level drop-in for the reference's pybind op `gridsample_grad2.grad2_2d`

@@ -130,7 +130,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == 6
+    assert lib.tt_abi_version() == 7
     assert b"bad argument" in lib.tt_strerror(-1)
 
 

@@ -23,6 +23,7 @@ SYMBOLS = [
     "tt_strerror", "tt_abi_version", "tt_planes_pack", "tt_planes_unpack_grad", "tt_query_points",
     "tt_query_field", "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2",
     "tt_march_fwd", "tt_march_bwd", "tt_sample_uniform", "tt_sample_importance",
+    "tt_points_bwd_geo", "tt_points_bwd_tex",
 ]
 
 
@@ -111,6 +112,8 @@ def load() -> ctypes.CDLL:
         "tt_render_bwd_tex": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 4 + [_P, _wp, _P],
         "tt_march_fwd": [_P, _P, _P, _cfgp] + [_P] * 11,
         "tt_march_bwd": [_P, _P, _P, _cfgp] + [_P] * 16,
+        "tt_points_bwd_geo": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _wp, _P],
+        "tt_points_bwd_tex": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _wp, _P],
         "tt_sample_uniform": [_I64, _I32, _F, _F, _P, _P, _P, _P],
         "tt_sample_importance": [_P, _P, _P, _I64, _I32, _I32, _F, _F, _P, _P, _P, _P],
         "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],

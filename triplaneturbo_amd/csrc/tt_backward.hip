@@ -270,7 +270,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         const size_t pofs = (size_t)(view / cfg.views_per_prompt) * plane_stride;
         const float* pbase = p.packed + pofs;
         const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
-        const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
+        // rays_d == null: explicit points (tt_points_bwd_*), x = rays_o exactly
+        const float dx = p.rays_d ? p.rays_d[ray * 3 + 0] : 0.f, dy = p.rays_d ? p.rays_d[ray * 3 + 1] : 0.f,
+                    dz = p.rays_d ? p.rays_d[ray * 3 + 2] : 0.f;
         const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
 #pragma nounroll
         for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb) {
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             float sbar = rvalid ? up[0] : 0.f, gbx = rvalid ? up[1] : 0.f, gby = rvalid ? up[2] : 0.f,
                   gbz = rvalid ? up[3] : 0.f;
             if (!__any(sbar != 0.f || gbx != 0.f || gby != 0.f || gbz != 0.f)) continue;  // exact
-            const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
+            const float ts = p.rays_d ? p.t_starts[sidx] : 0.f, te = p.rays_d ? p.t_ends[sidx] : 0.f;
             float tm, px, py, pz;
             sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
             const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius),
@@ -442,7 +444,8 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
       const int view = (int)(ray / cfg.rays_per_view);
       const size_t pofs = (size_t)(view / cfg.views_per_prompt) * plane_stride;
       const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
-      const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
+      const float dx = p.rays_d ? p.rays_d[ray * 3 + 0] : 0.f, dy = p.rays_d ? p.rays_d[ray * 3 + 1] : 0.f,
+                  dz = p.rays_d ? p.rays_d[ray * 3 + 2] : 0.f;
       float grgb[3];
 #pragma unroll
       for (int o = 0; o < 3; ++o) grgb[o] = p.g_rgb ? p.g_rgb[ray * 3 + o] : 0.f;
@@ -455,17 +458,17 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         // ---- upstream: cbar_o = shrink * w_i * g_rgb[ray,o] * 1.002 * s(1-s) + g_features ----
         float cb[3];
         {
-            const float wgt = valid ? p.weights[sidx] : 0.f;
+            const float wgt = (valid && p.weights) ? p.weights[sidx] : 0.f;  // null: no march above (points)
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
-                const float s = sigmoidf_(p.features[sidx * 3 + o]);
+                const float s = p.weights ? sigmoidf_(p.features[sidx * 3 + o]) : 0.f;
                 float v = shrink * wgt * grgb[o] * 1.002f * s * (1.f - s);
                 if (p.g_features) v += p.g_features[sidx * 3 + o];
                 cb[o] = valid ? v : 0.f;
             }
         }
         if (!__any(cb[0] != 0.f || cb[1] != 0.f || cb[2] != 0.f)) continue;  // exact: nothing flows back
-        const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
+        const float ts = p.rays_d ? p.t_starts[sidx] : 0.f, te = p.rays_d ? p.t_ends[sidx] : 0.f;
         float tm, px, py, pz;
         sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
         const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius), Z = scale_coord(pz, cfg.radius);
@@ -681,6 +684,120 @@ extern "C" int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, c
     p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom, 1);
     long long blocks = persistent_blocks(p.n_items, cus);
     if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
+    p.queue = tt_queue_counters((hipStream_t)stream);
+    if (!p.queue) return TT_ERR_DEVICE;
+    hipLaunchKernelGGL(k_decode_bwd_tex, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return tt_check_launch();
+}
+
+// ---- backward of the per-point queries (tt_query_points / tt_query_field): the same decode-backward kernels, with
+// "rays" of one sample whose origin is the point (direction null => x = o exactly) ----
+__global__ void k_interleave_ws(const float* __restrict__ g_sdf, const float* __restrict__ g_sdf_grad,
+                                float* __restrict__ ws, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f32x4 o = {g_sdf ? g_sdf[i] : 0.f, g_sdf_grad ? g_sdf_grad[i * 3 + 0] : 0.f,
+               g_sdf_grad ? g_sdf_grad[i * 3 + 1] : 0.f, g_sdf_grad ? g_sdf_grad[i * 3 + 2] : 0.f};
+    *reinterpret_cast<f32x4*>(ws + i * 4) = o;
+}
+
+static int points_cfg(tt_render_cfg* c, int32_t n_batch, int64_t n_points, int32_t n_prompts,
+                      int32_t views_per_prompt, int32_t plane_h, int32_t plane_w, float radius, float sdf_bias_radius,
+                      int32_t grad_copies) {
+    if (n_batch <= 0 || n_points <= 0 || n_prompts <= 0 || views_per_prompt <= 0) return TT_ERR_BAD_ARG;
+    if ((int64_t)n_prompts * views_per_prompt != n_batch || n_points > 0x7fffffffLL) return TT_ERR_BAD_ARG;
+    c->n_prompts = n_prompts;
+    c->views_per_prompt = views_per_prompt;
+    c->plane_h = plane_h;
+    c->plane_w = plane_w;
+    c->rays_per_view = (int32_t)n_points;
+    c->n_samples = 1;
+    c->n_rays = (int64_t)n_batch * n_points;
+    c->radius = radius;
+    c->sdf_bias_radius = sdf_bias_radius;
+    c->inv_std = 1.f;  // unused by the decode kernels
+    c->cos_anneal_ratio = 1.f;
+    c->rgb_grad_shrink = 1.f;
+    c->flags = 0;
+    c->image_w = 0;
+    c->tile_sb = 1;
+    c->grad_copies = grad_copies;
+    return tt_validate_cfg(c);
+}
+
+extern "C" int tt_points_bwd_geo(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
+                                 int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h,
+                                 int32_t plane_w, float radius, float sdf_bias_radius, const float* g_sdf,
+                                 const float* g_sdf_grad, float* workspace, float* grad_packed,
+                                 const tt_mlp_grads* grads, void* stream) {
+    tt_render_cfg cfg;
+    int st = points_cfg(&cfg, n_batch, n_points, n_prompts, views_per_prompt, plane_h, plane_w, radius,
+                        sdf_bias_radius, 1);
+    if (st != TT_OK) return st;
+    if (!packed || !w || !points || !workspace || !grad_packed || !grads || (!g_sdf && !g_sdf_grad))
+        return TT_ERR_BAD_ARG;
+    if (!w->w1 || !w->w2 || !w->w3 || !grads->w1 || !grads->w2 || !grads->w3) return TT_ERR_BAD_ARG;
+    int cus = tt_num_cus();
+    if (cus <= 0) return TT_ERR_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = cfg.n_rays;
+    hipLaunchKernelGGL(k_interleave_ws, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g_sdf, g_sdf_grad,
+                       workspace, n);
+    st = tt_check_launch();
+    if (st != TT_OK) return st;
+    BwdGeoParams p;
+    p.packed = packed;
+    p.w = to_ptrs(w);
+    p.rays_o = points;
+    p.rays_d = nullptr;
+    p.t_starts = nullptr;
+    p.t_ends = nullptr;
+    p.cfg = cfg;
+    p.ws = workspace;
+    p.grad_packed = grad_packed;
+    p.n_copies = 1;
+    p.grads = to_gptrs(grads);
+    p.n_items = tt_make_geom(&cfg, 4LL * cus, &p.geom, 1);
+    if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
+    long long blocks = persistent_blocks(p.n_items, cus);
+    p.queue = tt_queue_counters(s);
+    if (!p.queue) return TT_ERR_DEVICE;
+    hipLaunchKernelGGL(k_decode_bwd_geo, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return tt_check_launch();
+}
+
+extern "C" int tt_points_bwd_tex(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
+                                 int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h,
+                                 int32_t plane_w, float radius, int32_t plane_base, const float* g_features,
+                                 float* grad_packed, const tt_mlp_grads* grads, void* stream) {
+    tt_render_cfg cfg;
+    int st = points_cfg(&cfg, n_batch, n_points, n_prompts, views_per_prompt, plane_h, plane_w, radius, 0.5f, 1);
+    if (st != TT_OK) return st;
+    if (!packed || !w || !points || !g_features || !grad_packed || !grads) return TT_ERR_BAD_ARG;
+    if (!w->v1 || !w->v2 || !w->v3 || !grads->v1 || !grads->v2 || !grads->v3) return TT_ERR_BAD_ARG;
+    if (plane_base != 0 && plane_base != 3) return TT_ERR_BAD_ARG;
+    int cus = tt_num_cus();
+    if (cus <= 0) return TT_ERR_DEVICE;
+    // the kernel addresses planes 3..5 of each prompt; plane_base = 0 slides that window onto planes 0..2
+    const ptrdiff_t shift = (ptrdiff_t)(plane_base - 3) * plane_h * plane_w * TT_C;
+    BwdTexParams p;
+    p.packed = packed + shift;
+    p.w = to_ptrs(w);
+    p.rays_o = points;
+    p.rays_d = nullptr;
+    p.t_starts = nullptr;
+    p.t_ends = nullptr;
+    p.cfg = cfg;
+    p.weights = nullptr;
+    p.features = nullptr;
+    p.g_rgb = nullptr;
+    p.g_features = g_features;
+    p.grad_packed = grad_packed + shift;
+    p.n_copies = 1;
+    p.grads = to_gptrs(grads);
+    p.n_items = tt_make_geom(&cfg, 4LL * cus, &p.geom, 1);
+    if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
+    long long blocks = persistent_blocks(p.n_items, cus);
     p.queue = tt_queue_counters((hipStream_t)stream);
     if (!p.queue) return TT_ERR_DEVICE;
     hipLaunchKernelGGL(k_decode_bwd_tex, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);

@@ -101,18 +101,31 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
     def mlp_weights(self) -> Tuple[list, list]:
         return self.sdf_network.weights(), self.feature_network.weights()
 
-    @torch.no_grad()
+    def _wants_grad(self, space_cache: Tensor, nets) -> bool:
+        return torch.is_grad_enabled() and (space_cache.requires_grad or any(
+            w.requires_grad for net in nets for w in net))
+
     def forward(self, points: Tensor, space_cache: Tensor, output_normal: bool = False) -> Dict[str, Tensor]:
         """few_step...:273-351.  points (B,N,3); space_cache (P,6,32,H,W) with B a multiple of P (view b reads
-        prompt b // (B/P)).  Inference-style query (no autograd graph)."""
+        prompt b // (B/P)).  Under autograd (training-time per-point decode, e.g. the raster path
+        generative_space_mesh_rasterize_renderer.py:321-376) the outputs are connected to space_cache and the MLP
+        weights, second order through sdf_grad included; the points themselves are constants."""
         B, N, _ = points.shape
         P = space_cache.shape[0]
-        packed = ops.planes_pack(space_cache.detach())
         sw, fw = self.mlp_weights()
-        sdf, grad, feat = ops.query_points(packed, [w.detach() for w in sw], [w.detach() for w in fw],
-                                           points.detach().float(), views_per_prompt=B // P,
-                                           radius=self.cfg.radius, sdf_bias_radius=float(self.cfg.sdf_bias_params),
-                                           need_normal=output_normal, need_features=True)
+        pts = points.detach().float()
+        if self._wants_grad(space_cache, (sw, fw)):
+            sdf, grad, feat = ops.query_points_grad(space_cache, sw, fw, pts, views_per_prompt=B // P,
+                                                    radius=self.cfg.radius,
+                                                    sdf_bias_radius=float(self.cfg.sdf_bias_params),
+                                                    need_normal=output_normal)
+        else:
+            with torch.no_grad():
+                packed = ops.planes_pack(space_cache.detach())
+                sdf, grad, feat = ops.query_points(packed, [w.detach() for w in sw], [w.detach() for w in fw], pts,
+                                                   views_per_prompt=B // P, radius=self.cfg.radius,
+                                                   sdf_bias_radius=float(self.cfg.sdf_bias_params),
+                                                   need_normal=output_normal, need_features=True)
         bias = (points.reshape(-1, 3) ** 2).sum(-1, keepdim=True).sqrt() - float(self.cfg.sdf_bias_params)
         out = {"sdf": sdf, "sdf_orig": sdf - bias, "features": feat}
         if output_normal:
@@ -133,19 +146,24 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
                                      need_features=False)
         return sdf.reshape(*points.shape[:-1], 1)
 
-    @torch.no_grad()
     def forward_field(self, points: Tensor, space_cache: Tensor):
-        """few_step...:375-394: sdf (*N,1) and, with isosurface_deformable_grid, deformation (*N,3)."""
+        """few_step...:375-394: sdf (*N,1) and, with isosurface_deformable_grid, deformation (*N,3).  Under autograd
+        (the mesh renderer's grid query in training, generative_space_mesh_rasterize_renderer.py:428-452) both are
+        connected to space_cache, the sdf net and the deformation net."""
         if not self.cfg.isosurface_deformable_grid:
             return self.forward_sdf(points, space_cache), None
         B = points.shape[0]
-        pts = points.reshape(B, -1, 3)
-        packed = ops.planes_pack(space_cache.detach())
+        pts = points.reshape(B, -1, 3).detach().float()
         sw, _ = self.mlp_weights()
-        sdf, deform = ops.query_field(packed, [w.detach() for w in sw],
-                                      [w.detach() for w in self.deformation_network.weights()], pts.float(),
-                                      views_per_prompt=B // space_cache.shape[0], radius=self.cfg.radius,
-                                      sdf_bias_radius=float(self.cfg.sdf_bias_params))
+        dw = self.deformation_network.weights()
+        kw = dict(views_per_prompt=B // space_cache.shape[0], radius=self.cfg.radius,
+                  sdf_bias_radius=float(self.cfg.sdf_bias_params))
+        if self._wants_grad(space_cache, (sw, dw)):
+            sdf, deform = ops.query_field_grad(space_cache, sw, dw, pts, **kw)
+        else:
+            with torch.no_grad():
+                sdf, deform = ops.query_field(ops.planes_pack(space_cache.detach()), [w.detach() for w in sw],
+                                              [w.detach() for w in dw], pts, **kw)
         return sdf.reshape(*points.shape[:-1], 1), deform.reshape(*points.shape[:-1], 3)
 
     def forward_level(self, field: Tensor, threshold: float) -> Tensor:

@@ -162,6 +162,117 @@ def query_field(packed: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tens
     return sdf, deform
 
 
+class _QueryPointsFn(torch.autograd.Function):
+    """Differentiable per-point decode (geometry.forward in training, few_step...:273-351): forward =
+    tt_planes_pack + tt_query_points, backward = tt_points_bwd_geo (sdf and, through the second-order chain,
+    sdf_grad) + tt_points_bwd_tex (features) + tt_planes_unpack_grad.  Differentiable inputs: space_cache and the
+    six MLP matrices; the points are constants."""
+
+    @staticmethod
+    def forward(ctx, space_cache, w1, w2, w3, v1, v2, v3, points, views_per_prompt, radius, sdf_bias_radius,
+                need_normal):
+        ctx.set_materialize_grads(False)
+        packed = planes_pack(space_cache)
+        sdf, grad, feat = query_points(packed, (w1, w2, w3), (v1, v2, v3), points, views_per_prompt, radius,
+                                       sdf_bias_radius, need_normal=need_normal, need_features=True)
+        ctx.save_for_backward(packed, w1, w2, w3, v1, v2, v3, points)
+        ctx.meta = (views_per_prompt, radius, sdf_bias_radius)
+        if grad is None:
+            grad = sdf.new_zeros((sdf.shape[0], 3))
+            ctx.mark_non_differentiable(grad)
+        return sdf, grad, feat
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sdf, g_grad, g_feat):
+        packed, w1, w2, w3, v1, v2, v3, points = ctx.saved_tensors
+        vpp, radius, bias_r = ctx.meta
+        B, N, _ = points.shape
+        P, _, H, W, _ = packed.shape
+        wst, keep = _weights_struct((w1, w2, w3), (v1, v2, v3))
+        grad_packed = torch.zeros_like(packed)
+        gw = [torch.zeros_like(t) for t in (w1, w2, w3, v1, v2, v3)]
+        gst = _grads_struct(gw)
+        lib = _lib.load()
+        c = lambda t: None if t is None else t.contiguous()
+        g_sdf, g_grad, g_feat = c(g_sdf), c(g_grad), c(g_feat)
+        if g_sdf is not None or g_grad is not None:
+            ws = torch.empty((B * N, 4), device=packed.device, dtype=torch.float32)
+            st = lib.tt_points_bwd_geo(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius,
+                                       bias_r, _ptr(g_sdf), _ptr(g_grad), _ptr(ws), _ptr(grad_packed),
+                                       ctypes.byref(gst), _stream())
+            _lib.check(st, "tt_points_bwd_geo")
+        if g_feat is not None:
+            st = lib.tt_points_bwd_tex(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius, 3,
+                                       _ptr(g_feat), _ptr(grad_packed), ctypes.byref(gst), _stream())
+            _lib.check(st, "tt_points_bwd_tex")
+        g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
+        return (g_cache, *gw, None, None, None, None, None)
+
+
+def query_points_grad(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], points: Tensor,
+                      views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5,
+                      need_normal: bool = True):
+    """Differentiable per-point decode: sdf (B*N,1), sdf_grad (B*N,3) (zeros, non-differentiable, when
+    need_normal is False), features (B*N,3); autograd-connected to space_cache and the six MLP matrices."""
+    return _QueryPointsFn.apply(space_cache, sdf_w[0], sdf_w[1], sdf_w[2], feat_w[0], feat_w[1], feat_w[2],
+                                _chk(points, "points"), int(views_per_prompt), float(radius), float(sdf_bias_radius),
+                                bool(need_normal))
+
+
+class _QueryFieldFn(torch.autograd.Function):
+    """Differentiable implicit-field query (forward_field in training, few_step...:375-394; caller
+    generative_space_mesh_rasterize_renderer.py:428-452): forward = tt_query_field, backward = tt_points_bwd_geo for
+    the sdf head + tt_points_bwd_tex on the geometry planes for the deformation head (a 32->64->64->3 net on the SUM
+    of the three planes is a 96->64->64->3 net with first-layer matrix [U1 U1 U1] on their concatenation)."""
+
+    @staticmethod
+    def forward(ctx, space_cache, w1, w2, w3, d1, d2, d3, points, views_per_prompt, radius, sdf_bias_radius):
+        ctx.set_materialize_grads(False)
+        packed = planes_pack(space_cache)
+        sdf, deform = query_field(packed, (w1, w2, w3), (d1, d2, d3), points, views_per_prompt, radius,
+                                  sdf_bias_radius)
+        ctx.save_for_backward(packed, w1, w2, w3, d1, d2, d3, points)
+        ctx.meta = (views_per_prompt, radius, sdf_bias_radius)
+        return sdf, deform
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sdf, g_def):
+        packed, w1, w2, w3, d1, d2, d3, points = ctx.saved_tensors
+        vpp, radius, bias_r = ctx.meta
+        B, N, _ = points.shape
+        P, _, H, W, _ = packed.shape
+        d1x3 = d1.repeat(1, 3).contiguous()  # (64, 96) = [U1 U1 U1]
+        wst = _lib.MlpWeights(*[_ptr(t) for t in (w1.contiguous(), w2.contiguous(), w3.contiguous(), d1x3,
+                                                  d2.contiguous(), d3.contiguous())])
+        grad_packed = torch.zeros_like(packed)
+        gw = [torch.zeros_like(t) for t in (w1, w2, w3, d1x3, d2, d3)]
+        gst = _grads_struct(gw)
+        lib = _lib.load()
+        if g_sdf is not None:
+            ws = torch.empty((B * N, 4), device=packed.device, dtype=torch.float32)
+            st = lib.tt_points_bwd_geo(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius,
+                                       bias_r, _ptr(g_sdf.contiguous()), None, _ptr(ws), _ptr(grad_packed),
+                                       ctypes.byref(gst), _stream())
+            _lib.check(st, "tt_points_bwd_geo")
+        if g_def is not None:
+            st = lib.tt_points_bwd_tex(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius, 0,
+                                       _ptr(g_def.contiguous()), _ptr(grad_packed), ctypes.byref(gst), _stream())
+            _lib.check(st, "tt_points_bwd_tex")
+        gw[3] = gw[3].view(64, 3, 32).sum(dim=1)
+        g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
+        return (g_cache, *gw, None, None, None, None)
+
+
+def query_field_grad(space_cache: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tensor], points: Tensor,
+                     views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5):
+    """Differentiable field query: sdf (B*N,1), deformation (B*N,3); autograd-connected to space_cache, the sdf net
+    and the deformation net."""
+    return _QueryFieldFn.apply(space_cache, sdf_w[0], sdf_w[1], sdf_w[2], deform_w[0], deform_w[1], deform_w[2],
+                               _chk(points, "points"), int(views_per_prompt), float(radius), float(sdf_bias_radius))
+
+
 def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, rc: RenderConfig,
               per_sample: bool, image_w: int = 0) -> "_lib.RenderCfg":
     P, _, H, W, _ = packed.shape
