@@ -41,6 +41,9 @@
  *   tt_points_bwd_geo /     the autograd backward of tt_query_points / tt_query_field w.r.t. planes and MLP weights
  *   tt_points_bwd_tex       (training-time callers: generative_space_mesh_rasterize_renderer.py:428-452 field
  *                           query, :321-376 per-pixel geometry decode); same kernels as tt_render_bwd_*.
+ *   tt_hashgrid_fwd / _bwd  tiny-cuda-nn's `HashGrid` encoding as used by the background
+ *                           (multi_prompt_neural_environment_hashgrid_map_background.py:25-34,54,104-105 via
+ *                           threestudio/models/networks.py:17-26,54-64); tcnn is CUDA-only and un-vendored.
  *   tt_grid_sample_2d_grad2 gridsample_cuda.cpp:26-37 `grad2_2d` itself (operator-level drop-in).
  */
 #ifndef TT_ABI_H
@@ -52,7 +55,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 7
+#define TT_ABI_VERSION 8
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -226,6 +229,23 @@ int tt_points_bwd_tex(const float* packed, const tt_mlp_weights* w, const float*
                       int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
                       float radius, int32_t plane_base, const float* g_features, float* grad_packed,
                       const tt_mlp_grads* grads, void* stream);
+
+/* Multiresolution hash encoding of 3-D points in [0,1]^3 (tcnn "HashGrid", Linear interpolation, fp32).
+ * params: flat table, level-major, entry-major, feature-minor (tcnn's `params` layout), tt_hashgrid_n_params floats
+ * (negative tt_status on a bad config); x (n,3); out / g_out (n, n_levels*n_features_per_level) row-major.
+ * _bwd accumulates d/d params into grad_params (caller zero-fills); no gradient w.r.t. x. */
+typedef struct {
+    int32_t n_levels;             /* <= 16 */
+    int32_t n_features_per_level; /* 1, 2, 4 or 8 */
+    int32_t log2_hashmap_size;
+    int32_t base_resolution;
+    float per_level_scale;
+} tt_hashgrid_cfg;
+int64_t tt_hashgrid_n_params(const tt_hashgrid_cfg* cfg);
+int tt_hashgrid_fwd(const float* x, int64_t n, const float* params, const tt_hashgrid_cfg* cfg, float* out,
+                    void* stream);
+int tt_hashgrid_bwd(const float* x, int64_t n, const float* g_out, const tt_hashgrid_cfg* cfg, float* grad_params,
+                    void* stream);
 
 /* Operator-level drop-in for the reference's pybind op `gridsample_grad2.grad2_2d`
  * (gridsample_cuda.cpp:26-37): backward of aten::grid_sampler_2d_backward, bilinear.  Contiguous fp32:

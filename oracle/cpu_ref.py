@@ -19,6 +19,13 @@ Parity status
   has no tests for it => **parity unpinned** at that boundary; the restatement
   follows nerfacc's published semantics and the reference's call sites.
 
+* background hash encoding: tiny-cuda-nn (README.md:74, requirements.txt:6 --
+  an un-vendored, UNPINNED git master dependency with no ROCm build) provides
+  ``HashGrid``; ``hashgrid_*`` below restate its published algorithm (Mueller
+  et al. 2022 + tcnn ``grid.h``: per-level scale/resolution, dense vs hashed
+  index, trilinear interpolation) in fp32 => **parity unpinned** there too
+  (tcnn itself computes this op in fp16).
+
 Every function cites the reference file:line it follows (paths relative to
 /root/reference).  All functions are dtype-generic (fp32 follows the
 reference's op order; fp64 is used as the "exact" arbiter).
@@ -341,6 +348,97 @@ def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Seq
                    normal=geo["normal"], shading_normal=geo["shading_normal"],
                    sdf_grad=geo["sdf_grad"], inv_std=torch.tensor(inv_std))
     return out
+
+
+# --------------------------------------------------------------------------
+# background: multiresolution hash encoding (tiny-cuda-nn HashGrid) + hypernet MLP
+# --------------------------------------------------------------------------
+HASH_PRIMES = (1, 2654435761, 805459861)
+
+
+def hashgrid_levels(n_levels: int = 8, log2_hashmap_size: int = 19, base_resolution: int = 4,
+                    per_level_scale: float = 1.8114473285278132):
+    """Per-level (offset, size, scale, resolution) of tcnn's GridEncoding (3-D, GridType::Hash):
+    scale_l = exp2(l * log2(per_level_scale)) * base_resolution - 1 (tcnn evaluates this with fp32 libm calls; here
+    and in tt_hashgrid.hip it is evaluated in double from the fp32 per_level_scale and rounded once to fp32, so that
+    it is libm-independent), resolution_l = ceil(scale_l) + 1,
+    size_l = min(next_multiple(resolution_l^3, 8), 2^log2_hashmap_size); offsets are the running sum.
+    (defaults = multi_prompt_neural_environment_hashgrid_map_background.py:25-34)"""
+    import numpy as np
+    levels, offset = [], 0
+    l2 = math.log2(float(np.float32(per_level_scale)))
+    for l in range(n_levels):
+        scale = np.float32(2.0 ** (l * l2) * base_resolution - 1.0)
+        res = int(math.ceil(float(scale))) + 1
+        size = min((res ** 3 + 7) // 8 * 8, 1 << log2_hashmap_size) if res ** 3 < 2 ** 31 else 1 << log2_hashmap_size
+        levels.append((offset, size, float(scale), res))
+        offset += size
+    return levels, offset
+
+
+def hashgrid_encode(x: Tensor, params: Tensor, n_levels: int = 8, n_features: int = 2, log2_hashmap_size: int = 19,
+                    base_resolution: int = 4, per_level_scale: float = 1.8114473285278132) -> Tensor:
+    """tcnn kernel_grid (Linear interpolation): x (N,3) in [0,1]; params flat (total*F,) level-major, entry-major,
+    feature-minor; returns (N, n_levels*F).  Per level: pos = scale*x + 0.5, cell = floor(pos), frac = pos - cell;
+    corner index = dense x + y*res + z*res^2 when res^3 fits the level, else XOR of coord*prime (uint32), then
+    % size; weights = prod(frac or 1-frac)."""
+    levels, total = hashgrid_levels(n_levels, log2_hashmap_size, base_resolution, per_level_scale)
+    assert params.numel() == total * n_features
+    table = params.reshape(total, n_features)
+    outs = []
+    for (offset, size, scale, res) in levels:
+        pos = x * scale + 0.5
+        cell = torch.floor(pos)
+        frac = pos - cell
+        cell = cell.to(torch.int64)
+        dense = res ** 3 <= size
+        acc = 0
+        for corner in range(8):
+            w = 1
+            idx3 = []
+            for d in range(3):
+                if corner & (1 << d):
+                    w = w * frac[:, d]
+                    idx3.append(cell[:, d] + 1)
+                else:
+                    w = w * (1 - frac[:, d])
+                    idx3.append(cell[:, d])
+            if dense:
+                index = idx3[0] + idx3[1] * res + idx3[2] * res * res
+            else:
+                index = (idx3[0] * HASH_PRIMES[0]) & 0xFFFFFFFF
+                index = index ^ ((idx3[1] * HASH_PRIMES[1]) & 0xFFFFFFFF)
+                index = index ^ ((idx3[2] * HASH_PRIMES[2]) & 0xFFFFFFFF)
+            index = index % size
+            acc = acc + w[:, None] * table[offset + index]
+        outs.append(acc)
+    return torch.cat(outs, dim=1)
+
+
+def hypernet_background(dirs: Tensor, text_embed: Tensor, grid_params: Tensor, hyper: Sequence[Tensor],
+                        color_activation: str = "sigmoid-mipnerf", grid_cfg: Optional[dict] = None) -> Tensor:
+    """MultipromptNeuralHashgridEnvironmentMapBackground.forward
+    (multi_prompt_neural_environment_hashgrid_map_background.py:88-124) with LinearHyperNetwork
+    (geometry/hypernetwork.py:18-100, n_hidden_layers = 1): hyper = (W0 (64,c_dim), ln_w, ln_b, W1 (n_out,64), b1).
+    dirs (B,H,W,3) unit vectors; text_embed (P,c_dim), B a multiple of P."""
+    B, Hh, Ww, _ = dirs.shape
+    W0, ln_w, ln_b, W1, b1 = hyper
+    h = F.silu(F.layer_norm(F.linear(text_embed, W0), (W0.shape[0],), ln_w, ln_b))
+    out = F.linear(h, W1, b1)
+    enc_dim = (grid_cfg or {}).get("n_levels", 8) * (grid_cfg or {}).get("n_features", 2)
+    P = text_embed.shape[0]
+    m1 = out[:, :enc_dim * 64].reshape(P, enc_dim, 64)  # out_dims {"bg_weights": [enc, 64, 3]}
+    m2 = out[:, enc_dim * 64:enc_dim * 64 + 64 * 3].reshape(P, 64, 3)
+    enc = hashgrid_encode(((dirs + 1.0) / 2.0).reshape(-1, 3), grid_params, **(grid_cfg or {}))
+    enc = enc.reshape(B, Hh * Ww, enc_dim)
+    nv = B // P
+    x = torch.relu(torch.bmm(enc, m1.repeat_interleave(nv, dim=0)))
+    x = torch.bmm(x, m2.repeat_interleave(nv, dim=0)).reshape(B, Hh, Ww, 3)
+    if color_activation == "sigmoid-mipnerf":
+        return sigmoid_mipnerf(x)
+    if color_activation == "sigmoid":
+        return torch.sigmoid(x)
+    raise ValueError(color_activation)
 
 
 # --------------------------------------------------------------------------

@@ -95,6 +95,17 @@ def test_sampler_has_no_cpu_path():
         sampler.importance_sampling(lambda a, b: a, 5, 32, 16, 0.1, 4.0, 100.0, 0.05, device="cpu")
 
 
+def test_hashgrid_table_size_matches_oracle_levels():
+    """tt_hashgrid_n_params is a host-only function: per-level sizes follow tcnn's rule restated in the oracle."""
+    lib = _lib.load()
+    for cfg in ((8, 2, 19, 4, 1.8114473285278132), (5, 4, 10, 3, 2.0), (16, 2, 19, 16, 1.3819), (3, 1, 14, 16, 1.5)):
+        c = _lib.HashGridCfg(*cfg)
+        _, total = O.hashgrid_levels(cfg[0], cfg[2], cfg[3], cfg[4])
+        assert lib.tt_hashgrid_n_params(ctypes.byref(c)) == total * cfg[1], cfg
+    assert lib.tt_hashgrid_n_params(ctypes.byref(_lib.HashGridCfg(17, 2, 19, 4, 2.0))) == -1  # TT_ERR_BAD_ARG
+    assert lib.tt_hashgrid_n_params(ctypes.byref(_lib.HashGridCfg(8, 3, 19, 4, 2.0))) == -2  # TT_ERR_UNSUPPORTED
+
+
 def test_synthetic_inputs_match_oracle_conventions():
     a = synthetic.make_cameras(4, 6, 10, azimuth_start_deg=20.0)
     b = O.make_cameras(4, 6, 10, azimuth_start_deg=20.0)
@@ -130,7 +141,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == 7
+    assert lib.tt_abi_version() == 8
     assert b"bad argument" in lib.tt_strerror(-1)
 
 

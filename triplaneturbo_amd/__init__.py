@@ -11,7 +11,7 @@ from .registry import C, find, register  # noqa: F401
 
 
 def _register_plugins():
-    from . import geometry, renderer  # noqa: F401  (import = registration)
+    from . import background, geometry, renderer  # noqa: F401  (import = registration)
 
 
 _register_plugins()

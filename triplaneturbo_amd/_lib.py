@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libtt_hip.so")
-SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_host.cpp"]
+SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared", "-fno-gpu-rdc"]
 
 # every symbol include/tt_abi.h declares (tests check the header and this list agree)
@@ -23,7 +23,7 @@ SYMBOLS = [
     "tt_strerror", "tt_abi_version", "tt_planes_pack", "tt_planes_unpack_grad", "tt_query_points",
     "tt_query_field", "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2",
     "tt_march_fwd", "tt_march_bwd", "tt_sample_uniform", "tt_sample_importance",
-    "tt_points_bwd_geo", "tt_points_bwd_tex",
+    "tt_points_bwd_geo", "tt_points_bwd_tex", "tt_hashgrid_n_params", "tt_hashgrid_fwd", "tt_hashgrid_bwd",
 ]
 
 
@@ -79,6 +79,11 @@ class RenderCfg(ctypes.Structure):
     ]
 
 
+class HashGridCfg(ctypes.Structure):  # tt_hashgrid_cfg
+    _fields_ = [("n_levels", _I32), ("n_features_per_level", _I32), ("log2_hashmap_size", _I32),
+                ("base_resolution", _I32), ("per_level_scale", _F)]
+
+
 TT_R_PER_SAMPLE = 1
 TT_Q_NORMAL = 1
 TT_Q_TEX = 2
@@ -114,6 +119,9 @@ def load() -> ctypes.CDLL:
         "tt_march_bwd": [_P, _P, _P, _cfgp] + [_P] * 16,
         "tt_points_bwd_geo": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _wp, _P],
         "tt_points_bwd_tex": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _wp, _P],
+        "tt_hashgrid_n_params": [ctypes.POINTER(HashGridCfg)],
+        "tt_hashgrid_fwd": [_P, _I64, _P, ctypes.POINTER(HashGridCfg), _P, _P],
+        "tt_hashgrid_bwd": [_P, _I64, _P, ctypes.POINTER(HashGridCfg), _P, _P],
         "tt_sample_uniform": [_I64, _I32, _F, _F, _P, _P, _P, _P],
         "tt_sample_importance": [_P, _P, _P, _I64, _I32, _I32, _F, _F, _P, _P, _P, _P],
         "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
@@ -123,6 +131,7 @@ def load() -> ctypes.CDLL:
             getattr(lib, name).argtypes = argtypes
     for name in SYMBOLS[2:]:
         getattr(lib, name).restype = ctypes.c_int
+    lib.tt_hashgrid_n_params.restype = ctypes.c_int64
     _lib = lib
     return lib
 

@@ -60,8 +60,8 @@ class NoMaterial(BaseModule):
 
 @register("solid-color-background")
 class SolidColorBackground(BaseModule):
-    """Minimal background (the reference's hashgrid+hypernet background is a SURVEY 8(f) 'next' row): a constant
-    colour per ray, which is also what the reference uses at eval time (`eval_color`, yaml :114)."""
+    """Constant colour per ray -- what the reference uses at eval time (`eval_color`, yaml :114) and what the
+    benchmark uses.  The reference's training background is `background.py`."""
 
     @dataclass
     class Config(BaseModule.Config):
