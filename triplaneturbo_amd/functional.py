@@ -48,6 +48,10 @@ class LazyOutputs(dict):
     def get(self, key, default=None):
         return self[key] if key in self else default
 
+    def eager_keys(self):
+        """keys whose values exist already (iteration / keys() would run every pending thunk)"""
+        return list(super().keys())
+
     def _all(self):
         for k in list(self._lazy):
             self._materialise(k)
@@ -79,14 +83,17 @@ class LazyOutputs(dict):
 def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
                   rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, bg_color: Tensor, camera_distances: Tensor,
                   c2w: Tensor, rc: ops.RenderConfig, training: bool = True,
-                  normal_direction: str = "camera", comp_rgb_bg: Optional[Tensor] = None) -> Dict[str, Tensor]:
-    """rays_o/rays_d (B,H,W,3); t_starts/t_ends (B*H*W, S); bg_color (3,), (B*H*W,3) or (B,H,W,3)."""
+                  normal_direction: str = "camera", comp_rgb_bg: Optional[Tensor] = None,
+                  packed: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """rays_o/rays_d (B,H,W,3); t_starts/t_ends (B*H*W, S); bg_color (3,), (B*H*W,3) or (B,H,W,3);
+    packed = ops.pack_planes(space_cache) when the caller already has it."""
     B, Hh, Ww, _ = rays_o.shape
     n_rays = B * Hh * Ww
     S = t_starts.shape[1]
     ro = rays_o.reshape(n_rays, 3)
     rd = rays_d.reshape(n_rays, 3)
-    r = ops.render_samples(space_cache, sdf_w, feat_w, ro, rd, t_starts, t_ends, Hh * Ww, rc, image_w=Ww)
+    r = ops.render_samples(space_cache, sdf_w, feat_w, ro, rd, t_starts, t_ends, Hh * Ww, rc, image_w=Ww,
+                           packed=packed)
     opacity, depth, comp_rgb_fg, z_variance = r["opacity"], r["depth"], r["rgb_fg"], r["z_variance"]
 
     if bg_color.ndim == 1:

@@ -123,6 +123,27 @@ def planes_unpack_grad(grad_packed: Tensor) -> Tensor:
     return out
 
 
+class _PackPlanesFn(torch.autograd.Function):
+    """tt_planes_pack as a differentiable op: its backward is tt_planes_unpack_grad (the exact transpose)."""
+
+    @staticmethod
+    def forward(ctx, space_cache):
+        return planes_pack(space_cache)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_packed):
+        return planes_unpack_grad(grad_packed.contiguous())
+
+
+def pack_planes(space_cache: Tensor) -> Tensor:
+    """Differentiable planes_pack.  A caller that renders the same cache several times (PatchRenderer: global + patch,
+    plus the sampler's proposal pass) packs ONCE and hands `packed=` to render_samples / decode_rays: the packed
+    gradients of all renders are summed by autograd and unpacked once (the reference re-materialises a rotated copy
+    of the whole cache on every geometry call, few_step...:212-239)."""
+    return _PackPlanesFn.apply(space_cache)
+
+
 def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Sequence[Tensor]], points: Tensor,
                  views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5,
                  need_normal: bool = True, need_features: bool = True):
@@ -423,14 +444,13 @@ def _grads_struct(tensors: Sequence[Tensor]):
 
 
 class _TriplaneRenderFn(torch.autograd.Function):
-    """Differentiable fused render.  forward = tt_planes_pack + tt_render_fwd; backward = tt_render_bwd_geo +
-    tt_render_bwd_tex + tt_planes_unpack_grad.  Differentiable inputs: space_cache and the six MLP weights
-    (sample positions are constants: the reference's sampler runs under no_grad, estimators.py:22)."""
+    """Differentiable fused render on packed planes.  forward = tt_render_fwd; backward = tt_render_bwd_geo +
+    tt_render_bwd_tex.  Differentiable inputs: the packed planes (see pack_planes) and the six MLP weights (sample
+    positions are constants: the reference's sampler runs under no_grad, estimators.py:22)."""
 
     @staticmethod
-    def forward(ctx, space_cache, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, rays_per_view, rc,
+    def forward(ctx, packed, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, rays_per_view, rc,
                 image_w):
-        packed = planes_pack(space_cache)
         need_grad = any(ctx.needs_input_grad[:7])
         raw = render_forward_raw(packed, (w1, w2, w3), (v1, v2, v3), rays_o, rays_d, t_starts, t_ends, rays_per_view,
                                  rc, per_sample=True, image_w=image_w)
@@ -477,18 +497,23 @@ class _TriplaneRenderFn(torch.autograd.Function):
                 ctypes.byref(cfg), _ptr(weights), _ptr(features), _ptr(g_rgb), _ptr(g_features),
                 _ptr(grad_packed), ctypes.byref(gst), _stream())
         _lib.check(st, "tt_render_bwd_tex")
-        g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
-        return (g_cache, *gw, None, None, None, None, None, None, None)
+        g_packed = None
+        if ctx.needs_input_grad[0]:
+            g_packed = grad_packed[0] if copies == 1 else grad_packed.sum(dim=0)
+        return (g_packed, *gw, None, None, None, None, None, None, None)
 
 
-def render_samples(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
+def render_samples(space_cache: Optional[Tensor], sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
                    rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, rays_per_view: int, rc: RenderConfig,
-                   image_w: int = 0):
+                   image_w: int = 0, packed: Optional[Tensor] = None):
     """Differentiable render for explicit sample intervals.  Returns a dict of per-ray accumulators and
-    per-sample tensors (autograd-connected to space_cache and the MLP weights)."""
+    per-sample tensors (autograd-connected to space_cache and the MLP weights).  `packed` = pack_planes(space_cache)
+    made by the caller (then space_cache is not looked at)."""
     names = ("opacity", "depth", "rgb_fg", "z_variance", "normal_acc", "weights", "sdf", "sdf_grad", "features",
              "trans")
-    outs = _TriplaneRenderFn.apply(space_cache, sdf_w[0], sdf_w[1], sdf_w[2], feat_w[0], feat_w[1], feat_w[2],
+    if packed is None:
+        packed = pack_planes(space_cache)
+    outs = _TriplaneRenderFn.apply(packed, sdf_w[0], sdf_w[1], sdf_w[2], feat_w[0], feat_w[1], feat_w[2],
                                    rays_o.contiguous(), rays_d.contiguous(), t_starts.contiguous(),
                                    t_ends.contiguous(), rays_per_view, rc, int(image_w))
     return dict(zip(names, outs))

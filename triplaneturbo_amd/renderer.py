@@ -125,13 +125,13 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
                                 inv_std=float(self.variance.inv_std), cos_anneal_ratio=float(self.cos_anneal_ratio),
                                 rgb_grad_shrink=float(self.rgb_grad_shrink))
 
-    def sample(self, space_cache: Tensor, rays_o: Tensor, rays_d: Tensor, generator=None):
+    def sample(self, space_cache: Tensor, rays_o: Tensor, rays_d: Tensor, generator=None, packed=None):
         """ImportanceEstimator.sampling + prop_sigma_fn (estimators.py:22-101, renderer :243-316), no grad."""
         B, Hh, Ww, _ = rays_o.shape
         n_rays = B * Hh * Ww
         rc = self._render_config()
         sw, _ = self.geometry.mlp_weights()
-        packed = ops.planes_pack(space_cache.detach())
+        packed = ops.planes_pack(space_cache.detach()) if packed is None else packed.detach()
         ro, rd = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
 
         def sdf_fn(ts, te):
@@ -162,9 +162,14 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         if text_embed is not None:
             assert text_embed.shape[0] == P
         assert B % P == 0, "batch of views must be a multiple of the number of prompts"
+        grad_on = self.training and torch.is_grad_enabled()
+        packed = kwargs.pop("packed", None)  # PatchRenderer packs once for its two renders
+        if packed is None:
+            with (torch.enable_grad() if grad_on else torch.no_grad()):
+                packed = ops.pack_planes(space_cache)
         importance_sampled = t_starts is None
         if t_starts is None:
-            t_starts, t_ends = self.sample(space_cache, rays_o, rays_d)
+            t_starts, t_ends = self.sample(space_cache, rays_o, rays_d, packed=packed)
         if bg_color is None:
             text_bg = kwargs.get("text_embed_bg", text_embed)
             comp_rgb_bg = self.background(dirs=rays_d, text_embed=text_bg) if getattr(
@@ -176,12 +181,12 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         rc = self._render_config()
         if importance_sampled:  # consecutive samples crowd into the same texels: 4x2-pixel x 4-sample tiles
             rc.tile_sb = 4
-        grad_on = self.training and torch.is_grad_enabled()
         ctx = torch.enable_grad() if grad_on else torch.no_grad()
         with ctx:
             out = functional.volume_render(space_cache, sw, fw, rays_o, rays_d, t_starts, t_ends, bg_color,
                                            camera_distances, c2w, rc, training=self.training,
-                                           normal_direction=self.cfg.normal_direction, comp_rgb_bg=comp_rgb_bg)
+                                           normal_direction=self.cfg.normal_direction, comp_rgb_bg=comp_rgb_bg,
+                                           packed=packed)
         if self.training:
             out["inv_std"] = self.variance.inv_std
         return out
@@ -228,6 +233,10 @@ class PatchRenderer(BaseModule):
         B, H, W, _ = rays_o.shape
         if not self.base_renderer.training:
             return self.base_renderer(rays_o, rays_d, light_positions, bg_color, **kwargs)
+        sc = kwargs.get("space_cache")
+        if torch.is_tensor(sc) and kwargs.get("packed") is None:  # one pack (and one gradient unpack) for both renders
+            with (torch.enable_grad() if torch.is_grad_enabled() else torch.no_grad()):
+                kwargs["packed"] = ops.pack_planes(sc)
         ds = self.cfg.global_downsample
         g_o = F.interpolate(rays_o.permute(0, 3, 1, 2), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
         g_d = F.interpolate(rays_d.permute(0, 3, 1, 2), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
@@ -237,7 +246,8 @@ class PatchRenderer(BaseModule):
         py = torch.randint(0, H - PS, (1,)).item()
         out = self.base_renderer(rays_o[:, py:py + PS, px:px + PS].contiguous(),
                                  rays_d[:, py:py + PS, px:px + PS].contiguous(), light_positions, bg_color, **kwargs)
-        valid = [k for k in out if torch.is_tensor(out[k]) and out[k].ndim == out["comp_rgb"].ndim
+        eager = out.eager_keys() if hasattr(out, "eager_keys") else list(out)  # per-sample extras stay lazy
+        valid = [k for k in eager if torch.is_tensor(out[k]) and out[k].ndim == out["comp_rgb"].ndim
                  and out[k][..., 0].shape == out["comp_rgb"][..., 0].shape]
         for k in valid:
             up = F.interpolate(out_global[k].permute(0, 3, 1, 2), (H, W), mode="bilinear").permute(0, 2, 3, 1)
