@@ -11,6 +11,7 @@
 //
 // Everything per-sample is RECOMPUTED from the planes; the forward saves only trans / weights / features.
 #include "tt_device.h"
+#include "tt_mfma16.h"
 #include "tt_host.h"
 #include <stdlib.h>
 
@@ -227,17 +228,25 @@ struct BwdGeoParams {
 };
 
 #define GEO_SCRATCH_FLOATS (2 * 64 * XS)
+// split-fp16 weight images (tt_mfma16.h): W1, W2 at their fp32 offsets (same bytes), transposes appended
+#define GOFF_W1T LDS_GEO_FLOATS
+#define GOFF_W2T (GOFF_W1T + IMG16_FLOATS(32, 64))
+#define LDS_GEO16_FLOATS (GOFF_W2T + IMG16_FLOATS(64, 64))
 
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_GEO_FLOATS + 4 * (GEO_SCRATCH_FLOATS + 64)];
+    __shared__ __attribute__((aligned(16))) float L[LDS_GEO16_FLOATS + 4 * (GEO_SCRATCH_FLOATS + 64)];
     {
         MlpPtrs w = p.w;
-        lds_load_geo_weights(L, w);
+        stage_image16<64, 32, false>(L + OFF_W1, w.w1, 32);
+        stage_image16<64, 64, false>(L + OFF_W2, w.w2, 64);
+        lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
+        stage_image16<32, 64, true>(L + GOFF_W1T, w.w1, 32);
+        stage_image16<64, 64, true>(L + GOFF_W2T, w.w2, 64);
     }
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5, wave_in_blk = threadIdx.x >> 6;
-    float* Xs = L + LDS_GEO_FLOATS + wave_in_blk * (GEO_SCRATCH_FLOATS + 64);
+    float* Xs = L + LDS_GEO16_FLOATS + wave_in_blk * (GEO_SCRATCH_FLOATS + 64);
     float* Ys = Xs + 64 * XS;
     int* tags = reinterpret_cast<int*>(Ys + 64 * XS);
     tags[lane] = -1;
@@ -297,10 +306,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                                                   cs, coefs, cfg.flags));
             if (!any) continue;  // exact: no in-bounds texel => f = J = 0, every mask false
             float h1[32], h2[32], a2[32], a1[32], q[16];
-            mv_fwd<64, 32>(L + OFF_W1, f, h1, i, hi);
+            mv16<64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mv_fwd<64, 64>(L + OFF_W2, h1, h2, i, hi);
+            mv16<64, 64>(L + OFF_W2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
 #pragma unroll
@@ -309,10 +318,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
             }
-            mv_bwd<64, 64>(L + OFF_W2, a2, a1, i, hi);
+            mv16<64, 64>(L + GOFF_W2T, a2, a1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-            mv_bwd<32, 64>(L + OFF_W1, a1, q, i, hi);
+            mv16<32, 64>(L + GOFF_W1T, a1, q, i, hi);
             // ---- network + plane gradients ----
             {
                 float qb[16];
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 }
                 // a1bar = W1 qbar ; b1bar = m1 . a1bar ; v = sbar h1 + b1bar
                 float t1[32];
-                mv_fwd<64, 32>(L + OFF_W1, qb, t1, i, hi);
+                mv16<64, 32>(L + OFF_W1, qb, t1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) t1[r] = h1[r] > 0.f ? t1[r] : 0.f;  // b1bar
                 float v[32];
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 }
                 // a2bar = W2 b1bar ; dw3 += sbar h2 + m2 . a2bar
                 float t2[32];
-                mv_fwd<64, 64>(L + OFF_W2, t1, t2, i, hi);
+                mv16<64, 64>(L + OFF_W2, t1, t2, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) t2[r] = fmaf(sbar, h2[r], h2[r] > 0.f ? t2[r] : 0.f);
                 stage_rows<64>(Xs, t2, i, hi);

@@ -1,5 +1,6 @@
 // tt_forward.hip -- plane pack/unpack, per-point decode (tt_query_points) and the fused forward render.
 #include "tt_device.h"
+#include "tt_mfma16.h"
 #include "tt_host.h"
 
 #include <stdlib.h>
@@ -76,7 +77,12 @@ struct DecodeCfg {
 };
 
 // outputs are identical in both half-waves.  gq = J^T q (WITHOUT the sphere term).
-template <bool NEED_N, bool NEED_TEX>
+// F16: the weight images in L are split-fp16 images (tt_mfma16.h; W1^T / W2^T images at OFF_W1T / OFF_W2T)
+#define OFF_W1T LDS_W_FLOATS
+#define OFF_W2T (OFF_W1T + IMG16_FLOATS(32, 64))
+#define LDS_W16_FLOATS (OFF_W2T + IMG16_FLOATS(64, 64))
+
+template <bool NEED_N, bool NEED_TEX, bool F16 = false>
 __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, float px, float py, float pz,
                                            bool valid, int i, int hi, float& s0, float (&gq)[3], float (&c)[3]) {
     const float X = scale_coord(px, dc.radius), Y = scale_coord(py, dc.radius), Z = scale_coord(pz, dc.radius);
@@ -93,10 +99,16 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
             c[0] = c[1] = c[2] = t;
         } else if (__any(any)) {  // exact skip: e == 0 for the whole tile => features == 0 (bias-free MLP)
             float k1[32], k2[32];
-            mv_fwd<64, 96>(L + OFF_V1, e, k1, i, hi);
+            if (F16)
+                mv16<64, 96>(L + OFF_V1, e, k1, i, hi);
+            else
+                mv_fwd<64, 96>(L + OFF_V1, e, k1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
-            mv_fwd<64, 64>(L + OFF_V2, k1, k2, i, hi);
+            if (F16)
+                mv16<64, 64>(L + OFF_V2, k1, k2, i, hi);
+            else
+                mv_fwd<64, 64>(L + OFF_V2, k1, k2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) k2[r] = fmaxf(k2[r], 0.f);
 #pragma unroll
@@ -121,10 +133,16 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
             gq[2] = tz;
         } else if (__any(any)) {
             float h1[32], h2[32];
-            mv_fwd<64, 32>(L + OFF_W1, f, h1, i, hi);
+            if (F16)
+                mv16<64, 32>(L + OFF_W1, f, h1, i, hi);
+            else
+                mv_fwd<64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mv_fwd<64, 64>(L + OFF_W2, h1, h2, i, hi);
+            if (F16)
+                mv16<64, 64>(L + OFF_W2, h1, h2, i, hi);
+            else
+                mv_fwd<64, 64>(L + OFF_W2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
             s0 = dot_lds<64>(L + OFF_W3, h2, hi);
@@ -137,10 +155,16 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
                 }
-                mv_bwd<64, 64>(L + OFF_W2, a2, a1, i, hi);
+                if (F16)
+                    mv16<64, 64>(L + OFF_W2T, a2, a1, i, hi);
+                else
+                    mv_bwd<64, 64>(L + OFF_W2, a2, a1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-                mv_bwd<32, 64>(L + OFF_W1, a1, q, i, hi);
+                if (F16)
+                    mv16<32, 64>(L + OFF_W1T, a1, q, i, hi);
+                else
+                    mv_bwd<32, 64>(L + OFF_W1, a1, q, i, hi);
                 float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -318,13 +342,25 @@ struct DecodeRaysParams {
     float* features;
 };
 
+// 8 waves (2 per SIMD) share one set of split-fp16 weight images (93 KB: one workgroup per CU)
+#define DECODE_THREADS 512
 template <bool NEED_N, bool NEED_TEX>
-__global__ __launch_bounds__(256, 2) void k_decode_rays(DecodeRaysParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_W_FLOATS];
+__global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams p) {
+    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS];
     {
         MlpPtrs w = p.w;
-        lds_load_geo_weights(L, w);
-        if (NEED_TEX) lds_load_tex_weights(L, w);
+        stage_image16<64, 32, false>(L + OFF_W1, w.w1, 32);
+        stage_image16<64, 64, false>(L + OFF_W2, w.w2, 64);
+        lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
+        if (NEED_N) {
+            stage_image16<32, 64, true>(L + OFF_W1T, w.w1, 32);
+            stage_image16<64, 64, true>(L + OFF_W2T, w.w2, 64);
+        }
+        if (NEED_TEX) {
+            stage_image16<64, 96, false>(L + OFF_V1, w.v1, 96);
+            stage_image16<64, 64, false>(L + OFF_V2, w.v2, 64);
+            lds_load_matrix(L + OFF_V3, w.v3, 3, 64, 64);
+        }
     }
     __syncthreads();
     const tt_render_cfg& cfg = p.cfg;
@@ -364,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void k_decode_rays(DecodeRaysParams p) {
             float tm, px, py, pz;
             sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
             float s0, gq[3], c[3];
-            decode_fwd<NEED_N, NEED_TEX>(L, dc, px, py, pz, rvalid, i, hi, s0, gq, c);
+            decode_fwd<NEED_N, NEED_TEX, true>(L, dc, px, py, pz, rvalid, i, hi, s0, gq, c);
             float nrm;
             const float sdf = s0 + sphere_bias(px, py, pz, cfg.sdf_bias_radius, nrm);
             if (rvalid && hi == 0 && !(cfg.flags & TT_DBG_NO_STORE)) {
@@ -562,17 +598,17 @@ extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const
     p.sdf = sdf;
     p.sdf_grad = sdf_grad;
     p.features = features;
-    const long long slots = 2LL * cus * 4;  // 2 workgroups of 4 waves per CU (LDS 69 KB each)
+    const long long slots = (long long)cus * (DECODE_THREADS / 64);  // one 8-wave workgroup per CU (LDS 93 KB)
     p.n_items = tt_make_geom(cfg, slots, &p.geom, 1);
-    long long blocks = 2LL * cus;
-    long long need = (p.n_items + 3) / 4;
+    long long blocks = cus;
+    long long need = (p.n_items + 7) / 8;
     if (blocks > need) blocks = need;
     blocks = (blocks + 7) / 8 * 8;
     hipStream_t s = (hipStream_t)stream;
     if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
     p.queue = tt_queue_counters(s);
     if (!p.queue) return TT_ERR_DEVICE;
-    hipLaunchKernelGGL((k_decode_rays<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((k_decode_rays<true, true>), dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
     st = tt_check_launch();
     if (st != TT_OK) return st;
     return tt_launch_march_fwd(rays_d, t_starts, t_ends, cfg, sdf, sdf_grad, features, opacity, depth, rgb_fg,
@@ -605,13 +641,13 @@ extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, cons
     p.sdf = sdf;
     p.sdf_grad = sdf_grad;
     p.features = features;
-    const long long slots = 2LL * cus * 4;
+    const long long slots = (long long)cus * (DECODE_THREADS / 64);
     p.n_items = tt_make_geom(cfg, slots, &p.geom, 1);
-    long long blocks = 2LL * cus;
-    long long need = (p.n_items + 3) / 4;
+    long long blocks = cus;
+    long long need = (p.n_items + 7) / 8;
     if (blocks > need) blocks = need;
     blocks = (blocks + 7) / 8 * 8;
-    dim3 grid((unsigned)blocks), blk(256);
+    dim3 grid((unsigned)blocks), blk(DECODE_THREADS);
     hipStream_t s = (hipStream_t)stream;
     if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
     p.queue = tt_queue_counters(s);

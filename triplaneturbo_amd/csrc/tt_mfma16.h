@@ -1,0 +1,124 @@
+// tt_mfma16.h -- fp32-accurate mat-vec products on the fp16 matrix pipe (v_mfma_f32_32x32x16_f16, 16x the rate of
+// v_mfma_f32_32x32x2_f32 on gfx950).
+//
+// Every fp32 operand is split in two fp16 terms, v = hi + lo' / 2048 with hi = f16(v) and lo' = f16((v - hi) * 2048)
+// (v - hi is exact in fp32; the 2^11 factor keeps lo' out of the fp16 subnormals), so hi + lo'/2048 carries 22
+// significand bits.  A product keeps the three terms above 2^-22:
+//      a b  ~=  a_hi b_hi  +  (a_hi b_lo' + a_lo' b_hi) / 2048
+// = 3 MFMAs per 16-deep k-step (fp16 x fp16 products are exact, accumulation is fp32 inside the MFMA) instead of 8
+// fp32 MFMAs of twice the issue time: 5.3x less matrix-pipe time.  Relative error per product <= 2^-21 (round toward
+// zero conversions), i.e. fp32-grade for these 32..96-term dot products whose fp32 accumulation error is ~sqrt(K) 2^-24.
+//
+// Layout.  Activations stay in the LIDX register layout of tt_device.h (reg r of lane (j, hi) <-> element
+// (r&3) + 8(r>>2) + 4hi): the 8 registers 8s..8s+7 of a lane are the 8 k-slots that lane feeds to k-step s of a
+// 32x32x16 MFMA (B operand); which element sits in which slot does not matter as long as the A operand uses the same
+// assignment, so the weight image is stored pre-permuted: row R of a [ROWS][K] matrix holds, for k-step s, term t in
+// {hi, lo'} and half-wave h, the 8 halfs  W[R][16s + (j&3) + 8(j>>2) + 4h], j = 0..7  at
+//      R * (2K + 8) + ((2s + t) * 2 + h) * 8      (in halfs)
+// i.e. exactly the bytes and the 16-byte-per-lane, conflict-free read pattern of the fp32 image (row stride K+4
+// floats).  `W^T x` products use a second image built from the transposed matrix.
+#pragma once
+#include "tt_device.h"
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half_t;
+
+#define IMG16_FLOATS(ROWS, K) ((ROWS) * ((K) + 4)) /* LDS floats one image occupies */
+
+__device__ __forceinline__ void split16(float v, half_t& hi, half_t& lo) {
+    const h2_t p = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(v, 0.f));
+    hi = p.x;
+    const h2_t q = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz((v - (float)hi) * 2048.f, 0.f));
+    lo = q.x;
+}
+
+// Builds the image of M (ROWS x K).  src is row-major: M[R][c] = src[R * ld + c], or, with TRANSPOSED, the image of
+// src^T: M[R][c] = src[c * ld + R].  All threads of the workgroup take part; caller synchronises.
+template <int ROWS, int K, bool TRANSPOSED>
+__device__ __forceinline__ void stage_image16(float* dst_f, const float* __restrict__ src, int ld) {
+    half_t* dst = reinterpret_cast<half_t*>(dst_f);
+    constexpr int RS = 2 * K + 8;
+    for (int e = threadIdx.x; e < ROWS * K; e += blockDim.x) {
+        const int R = e / K, c = e - R * K;
+        const float v = TRANSPOSED ? src[(size_t)c * ld + R] : src[(size_t)R * ld + c];
+        half_t hi, lo;
+        split16(v, hi, lo);
+        // element c = 16 s + (j&3) + 8 (j>>2) + 4 h
+        const int s = c >> 4, w = c & 15;
+        const int h = (w >> 2) & 1, j = (w & 3) + 4 * (w >> 3);
+        half_t* p = dst + (size_t)R * RS + (size_t)(4 * s + h) * 8 + j;
+        p[0] = hi;   // term 0
+        p[16] = lo;  // term 1: +2 half-wave blocks of 8 halfs
+    }
+}
+
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+// y[NOUT] = M[NOUT][NIN] x[NIN], M given as an image; x, y in the LIDX register layout.
+// SCALED: every sample (= MFMA column = this lane and its partner lane ^ 32) is first normalised by the power of two
+// that brings its largest |x| into [0.5, 1) and the result is scaled back -- exact, and it makes the product
+// independent of the magnitude of x (gradient chains carry values of 1e-10 that fp16 cannot hold; columns of a
+// mat-vec are independent, so each gets its own exponent).
+template <int NOUT, int NIN, bool SCALED = true>
+__device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i,
+                                     int hi) {
+    constexpr int MT = NOUT / 32, KS = NIN / 16, RS = 2 * NIN + 8;
+    const half_t* row = reinterpret_cast<const half_t*>(img_f) + (size_t)i * RS + 8 * hi;
+    float sc = 1.f, sc2048 = 2048.f, un = 1.f, un2048 = 1.f / 2048.f;
+    if (SCALED) {
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < NIN / 2; ++r) m = fmaxf(m, __builtin_fabsf(x[r]));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        int E = (int)(__builtin_bit_cast(unsigned, m) >> 23);  // biased exponent (m >= 0)
+        E = E < 12 ? 12 : (E > 240 ? 240 : E);                 // keeps all four factors normal
+        sc = __builtin_bit_cast(float, (unsigned)(253 - E) << 23);         // 2^(126 - e): max |x| -> [0.5, 1)
+        sc2048 = __builtin_bit_cast(float, (unsigned)(264 - E) << 23);     // sc * 2^11
+        un = __builtin_bit_cast(float, (unsigned)(E + 1) << 23);           // 1 / sc
+        un2048 = __builtin_bit_cast(float, (unsigned)(E - 10) << 23);      // 1 / (sc * 2^11)
+    }
+    f32x16 acc_h[MT], acc_l[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        acc_h[m] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc_l[m] = acc_h[m];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        // split the 8 activations of this k-step
+        h8_t bh, bl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f2_t ab = {x[8 * s + 2 * j], x[8 * s + 2 * j + 1]};
+            const f2_t as = SCALED ? ab * sc : ab;  // exact (power of two)
+            const f2_t a2k = ab * sc2048;
+            const h2_t p = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(as.x, as.y));
+            const float ra = __builtin_fmaf((float)p.x, -2048.f, a2k.x);
+            const float rb = __builtin_fmaf((float)p.y, -2048.f, a2k.y);
+            const h2_t q = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+            bh[2 * j] = p.x;
+            bh[2 * j + 1] = p.y;
+            bl[2 * j] = q.x;
+            bl[2 * j + 1] = q.y;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const half_t* a = row + (size_t)(32 * m) * RS + 32 * s;
+            const h8_t ah = *reinterpret_cast<const h8_t*>(a);
+            const h8_t al = *reinterpret_cast<const h8_t*>(a + 16);
+            acc_h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_h[m], 0, 0, 0);
+            acc_l[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_l[m], 0, 0, 0);
+            acc_l[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_l[m], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (SCALED)
+                y[16 * m + k] = __builtin_fmaf(acc_l[m][k], un2048, acc_h[m][k] * un);
+            else
+                y[16 * m + k] = __builtin_fmaf(acc_l[m][k], 1.f / 2048.f, acc_h[m][k]);
+        }
+}
