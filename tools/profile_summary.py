@@ -47,8 +47,11 @@ m = lambda k, c: acc[k][c] / cnt[k][c] if cnt[k][c] else float("nan")
 L += ["", "## SQ counters (separate --pmc pass), per launch", "",
       f"MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (duration x {CLOCK_GHZ} GHz x {SIMDS} SIMDs)  [clock assumed under "
       "load]; wave life = SQ_WAVE_CYCLES x 4 / SQ_WAVES / (SQ_BUSY_CYCLES / 32 SEs): the average fraction of the "
-      "kernel a wave is resident (load balance; counters in quad-cycles / per-SE cycles).", "",
-      "| kernel | avg us | MFMA busy cycles | MFMA instr (busy/64) | MfmaUtil | wave life | WAIT_ANY/WAVE | WAIT_INST/WAVE |",
+      "kernel a wave is resident (load balance; counters in quad-cycles / per-SE cycles).  The forward decode and the "
+      "geometry backward run their mat-vec chains as split-fp16 MFMAs (3 x v_mfma_f32_32x32x16_f16 = 96 busy cycles per "
+      "16-deep k-step instead of 8 x v_mfma_f32_32x32x2_f32 = 512), so their MfmaUtil is LOW BY DESIGN: the same "
+      "algorithmic FLOPs need 5.3x less matrix-pipe time.", "",
+      "| kernel | avg us | MFMA busy cycles | MFMA busy ms / SIMD | MfmaUtil | wave life | WAIT_ANY/WAVE | WAIT_INST/WAVE |",
       "|---|---|---|---|---|---|---|---|"]
 for k in sorted(acc, key=lambda k: -avg_us.get(k, 0)):
     us = avg_us.get(k, float("nan"))
@@ -56,7 +59,7 @@ for k in sorted(acc, key=lambda k: -avg_us.get(k, 0)):
     util = busy / (us * 1e-6 * CLOCK_GHZ * 1e9 * SIMDS)
     wc, wv, bc = m(k, "SQ_WAVE_CYCLES"), m(k, "SQ_WAVES"), m(k, "SQ_BUSY_CYCLES")
     life = (wc * 4 / wv) / (bc / SES) if wv and bc else float("nan")
-    L.append(f"| {k} | {us:.1f} | {busy:.3e} | {busy / 64 / 1e6:.1f} M | {util:.2f} | {life:.2f} | "
+    L.append(f"| {k} | {us:.1f} | {busy:.3e} | {busy / SIMDS / (CLOCK_GHZ * 1e6):.2f} | {util:.2f} | {life:.2f} | "
              f"{m(k, 'SQ_WAIT_ANY') / wc:.2f} | {m(k, 'SQ_WAIT_INST_ANY') / wc:.2f} |")
 
 L += ["", "## HBM-side traffic (separate --pmc passes; FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE x2 = the gfx950 "
