@@ -409,22 +409,31 @@ struct BwdTexParams {
 #define TV2 (OFF_V2 - OFF_V1)
 #define TV3 (OFF_V3 - OFF_V1)
 #define TEX_SCRATCH_FLOATS ((64 + 96) * XS)
+// V1 and V1^T as split-fp16 images (tt_mfma16.h): k1 = V1 e and the per-plane ebar = V1_p^T k1bar run on the fp16
+// pipe.  V2 is used both ways too but stays ONE fp32 image with fp32 MFMAs: a second V2 image does not fit (the
+// kernel uses 163 072 of the CU's 163 840 LDS bytes) and its 160 accumulator registers leave little room anyway.
+#define TV1T TEX_W_FLOATS
+#define TEX_W16_FLOATS (TV1T + IMG16_FLOATS(96, 64))
 
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
-    __shared__ __attribute__((aligned(16))) float Lt[TEX_W_FLOATS + 4 * (TEX_SCRATCH_FLOATS + 64 + 96)];
+    __shared__ __attribute__((aligned(16))) float Lt[TEX_W16_FLOATS + 4 * (TEX_SCRATCH_FLOATS + 64)];
     {
         MlpPtrs w = p.w;
-        lds_load_matrix(Lt + TV1, w.v1, 64, 96, V1S);
+        stage_image16<64, 96, false>(Lt + TV1, w.v1, 96);  // same bytes as the fp32 image it replaces
         lds_load_matrix(Lt + TV2, w.v2, 64, 64, V2S);
         lds_load_matrix(Lt + TV3, w.v3, 3, 64, 64);
+        stage_image16<96, 64, true>(Lt + TV1T, w.v1, 96);
     }
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5, wave_in_blk = threadIdx.x >> 6;
-    float* Xs = Lt + TEX_W_FLOATS + wave_in_blk * (TEX_SCRATCH_FLOATS + 64 + 96);
+    float* Xs = Lt + TEX_W16_FLOATS + wave_in_blk * (TEX_SCRATCH_FLOATS + 64);
     float* Ys = Xs + 64 * XS;  // 96 rows
     int* tags = reinterpret_cast<int*>(Ys + 96 * XS);
-    float* Cb = reinterpret_cast<float*>(tags + 64);  // cbar of the tile, [3][32]
+    // cbar of the tile, [3][32]: in the 4 pad columns of Xs rows 0..23 (row r holds floats 4r..4r+3 of the 96) --
+    // stage_rows / the scatter matrix only touch columns 0..31 of a row
+    float* Cb = Xs + 32;
+#define CB_AT(idx) Cb[((idx) >> 2) * XS + ((idx)&3)]
     tags[lane] = -1;
     __syncthreads();
     const int S = cfg.n_samples;
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         const bool do_wgrad = !(cfg.flags & TT_DBG_NO_WGRAD);
         if (do_wgrad) stage_rows<96>(Ys, e, i, hi);
         float k1[32], k2[32];
-        mv_fwd<64, 96>(Lt + TV1, e, k1, i, hi);
+        mv16<64, 96>(Lt + TV1, e, k1, i, hi);
 #pragma unroll
         for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
         mv_fwd<64, 64>(Lt + TV2, k1, k2, i, hi);
@@ -498,16 +507,16 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         // ---- dV3[o][idx] += sum_s cbar_o[s] k2[idx][s]  (lane <-> idx through the transposition scratch) ----
         stage_rows<64>(Xs, k2, i, hi);
         if (hi == 0) {
-            Cb[0 * 32 + i] = cb[0];
-            Cb[1 * 32 + i] = cb[1];
-            Cb[2 * 32 + i] = cb[2];
+            CB_AT(0 * 32 + i) = cb[0];
+            CB_AT(1 * 32 + i) = cb[1];
+            CB_AT(2 * 32 + i) = cb[2];
         }
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             f32x4 kk = *reinterpret_cast<const f32x4*>(Xs + lane * XS + 4 * g);
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
-                f32x4 cc = *reinterpret_cast<const f32x4*>(Cb + o * 32 + 4 * g);
+                f32x4 cc = *reinterpret_cast<const f32x4*>(&CB_AT(o * 32 + 4 * g));
                 accV3[o] += (kk[0] * cc[0] + kk[1] * cc[1]) + (kk[2] * cc[2] + kk[3] * cc[3]);
             }
         }
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
                 for (int q4 = 0; q4 < 4; ++q4)  // absolute texel index, prompt included
                     aoff[q4] = (int)(pofs / TT_C) + (int)((3 + pl) * HW) + c.off[q4];
                 float eb[16];  // ebar of this plane = (V1[:, 32pl : 32pl+32])^T k1bar
-                mv_bwd<32, 64, V1S>(Lt + TV1 + 32 * pl, kb1, eb, i, hi);
+                mv16<32, 64>(Lt + TV1T + (size_t)32 * pl * (64 + 4), kb1, eb, i, hi);
                 float* Es = Ys;  // ebar staged as [sample][32], stride 33
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[r];
