@@ -4,8 +4,9 @@
  * This is the drop-in boundary of triplaneturbo_amd.  Every entry point is plain C:
  * raw DEVICE pointers (fp32 unless noted), explicit sizes, a config struct, a hipStream_t
  * passed as void*.  The caller (PyTorch-ROCm host code, or any FFI) allocates every output
- * and workspace; the library itself keeps one 16 KB device scratch per GPU (zeroed work-queue counters of the
- * per-sample kernels, rotating slots, so launches on different streams do not share counters); re-entrant; safe from one
+ * and workspace; the library itself keeps one 16 KB device scratch per GPU (work-queue counters of the per-sample
+ * kernels: rotating slots so launches on different streams do not share counters, self-resetting so a launch can be
+ * captured in a hipGraph; allocated at the first launch, which therefore must not be inside a capture); re-entrant; safe from one
  * host thread per device.  Return 0 on success, a negative tt_status on error (no C++
  * exceptions cross the boundary).  tt_strerror() maps codes to text.
  *

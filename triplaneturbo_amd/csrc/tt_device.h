@@ -451,6 +451,16 @@ __device__ __forceinline__ bool item_pop(ItemQueue& q, int order, int n_chunks, 
         }
         ++q.hop;
     }
+    // Every queue is empty for this wave: it will not pop again.  The LAST wave of the launch to get here zeroes the
+    // counters for the next launch that is handed this slot (no per-launch memset on the host: nothing to record
+    // when the launch is captured in a hipGraph, and replays find clean counters).
+    if ((threadIdx.x & 63) == 0) {
+        const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+        if (atomicAdd(q.ctr + 8, 1) == n_waves - 1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) atomicExch(q.ctr + k, 0);
+        }
+    }
     return false;
 }
 

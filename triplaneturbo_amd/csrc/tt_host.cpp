@@ -44,11 +44,11 @@ int* tt_queue_counters(hipStream_t stream) {
         if (!g_scratch[dev]) {
             void* ptr = nullptr;
             if (hipMalloc(&ptr, (size_t)kSlots * kSlotInts * sizeof(int)) != hipSuccess) return nullptr;
+            if (hipMemset(ptr, 0, (size_t)kSlots * kSlotInts * sizeof(int)) != hipSuccess) return nullptr;
             g_scratch[dev] = static_cast<int*>(ptr);
         }
         base = g_scratch[dev];
     }
-    int* slot = base + (size_t)(g_next_slot.fetch_add(1) % kSlots) * kSlotInts;
-    if (hipMemsetAsync(slot, 0, kSlotInts * sizeof(int), stream) != hipSuccess) return nullptr;
-    return slot;
+    (void)stream;  // the kernels leave their slot zeroed (item_pop): no memset to enqueue
+    return base + (size_t)(g_next_slot.fetch_add(1) % kSlots) * kSlotInts;
 }

@@ -14,6 +14,17 @@ from . import ops
 Tensor = torch.Tensor
 
 
+def _rot_world_to_cam(c2w: Tensor) -> Tensor:
+    """inverse(c2w)[:, :3, :3] (renderer :478-479) for affine camera matrices (last row 0 0 0 1), as the closed-form
+    inverse of the 3x3 block: rows of the inverse = cross products of the columns / det.  torch.inverse synchronises
+    with the host (pivoting info) and cannot be captured in a hipGraph; this is a handful of element-wise kernels."""
+    m = c2w[:, :3, :3]
+    c0, c1, c2 = m[:, :, 0], m[:, :, 1], m[:, :, 2]
+    r0, r1, r2 = torch.cross(c1, c2, dim=-1), torch.cross(c2, c0, dim=-1), torch.cross(c0, c1, dim=-1)
+    det = (c0 * r0).sum(dim=-1, keepdim=True)
+    return torch.stack([r0, r1, r2], dim=1) / det[:, :, None]
+
+
 class LazyOutputs(dict):
     """The renderer's output dict.  The reference returns a dozen per-sample "training extras" on every call
     (renderer :532-545) although a given loss configuration reads only a few of them; here they are registered as
@@ -122,15 +133,12 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
     comp_normal = F.normalize(r["normal_acc"], dim=-1)
     out["comp_normal"] = comp_normal.view(B, Hh, Ww, 3)
     if normal_direction == "camera":
-        bg_normal = 0.5 * torch.ones_like(comp_normal)
-        bg_normal[:, 2] = 1.0
+        # (device-side constants only: no host scalars written into GPU tensors, so the step can be graph-captured)
+        bg_normal = torch.cat([torch.full_like(comp_normal[:, :2], 0.5), torch.ones_like(comp_normal[:, :1])], dim=-1)
         bg_normal_white = torch.ones_like(comp_normal)
-        w2c = torch.inverse(c2w)
-        rot = w2c[:, :3, :3]
-        comp_normal_cam = comp_normal.view(B, -1, 3) @ rot.permute(0, 2, 1)
-        flip_x = torch.eye(3, device=comp_normal.device, dtype=comp_normal.dtype)
-        flip_x[0, 0] = -1
-        comp_normal_cam = (comp_normal_cam @ flip_x[None]).view(-1, 3)
+        rot = _rot_world_to_cam(c2w)
+        comp_normal_cam = (comp_normal.view(B, -1, 3) @ rot.permute(0, 2, 1)).view(-1, 3)
+        comp_normal_cam = torch.cat([-comp_normal_cam[:, :1], comp_normal_cam[:, 1:]], dim=-1)  # @ diag(-1, 1, 1)
         out["comp_normal_cam_vis"] = ((comp_normal_cam + 1.0) / 2.0 * opacity + (1 - opacity) * bg_normal).view(
             B, Hh, Ww, 3)
         out["comp_normal_cam_vis_white"] = (
@@ -140,7 +148,7 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
         nv = B // n_prompts
         bg_normal_white = torch.ones_like(comp_normal)
         c2w_front = c2w[0::nv].repeat_interleave(nv, dim=0)
-        rot = torch.inverse(c2w_front)[:, :3, :3]
+        rot = _rot_world_to_cam(c2w_front)
         comp_normal_front = (comp_normal.view(B, -1, 3) @ rot.permute(0, 2, 1)).view(-1, 3)
         out["comp_normal_cam_vis_white"] = (
             (comp_normal_front + 1.0) / 2.0 * opacity + (1 - opacity) * bg_normal_white).view(B, Hh, Ww, 3)
@@ -181,5 +189,5 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
                                                           - rc.sdf_bias_radius)))
         out.set_lazy("normal", lazy(normal))
         out.set_lazy("shading_normal", lazy(normal))
-        out["inv_std"] = torch.as_tensor(rc.inv_std, device=ro.device)
+        out["inv_std"] = torch.full((), float(rc.inv_std), device=ro.device)  # fill kernel, no host-to-device copy
     return out
