@@ -77,12 +77,12 @@ struct DecodeCfg {
 };
 
 // outputs are identical in both half-waves.  gq = J^T q (WITHOUT the sphere term).
-// F16: the weight images in L are split-fp16 images (tt_mfma16.h; W1^T / W2^T images at OFF_W1T / OFF_W2T)
+// the weight images in L are split-fp16 images (tt_mfma16.h); W1^T / W2^T images at OFF_W1T / OFF_W2T
 #define OFF_W1T LDS_W_FLOATS
 #define OFF_W2T (OFF_W1T + IMG16_FLOATS(32, 64))
 #define LDS_W16_FLOATS (OFF_W2T + IMG16_FLOATS(64, 64))
 
-template <bool NEED_N, bool NEED_TEX, bool F16 = false>
+template <bool NEED_N, bool NEED_TEX>
 __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, float px, float py, float pz,
                                            bool valid, int i, int hi, float& s0, float (&gq)[3], float (&c)[3]) {
     const float X = scale_coord(px, dc.radius), Y = scale_coord(py, dc.radius), Z = scale_coord(pz, dc.radius);
@@ -99,16 +99,10 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
             c[0] = c[1] = c[2] = t;
         } else if (__any(any)) {  // exact skip: e == 0 for the whole tile => features == 0 (bias-free MLP)
             float k1[32], k2[32];
-            if (F16)
-                mv16<64, 96>(L + OFF_V1, e, k1, i, hi);
-            else
-                mv_fwd<64, 96>(L + OFF_V1, e, k1, i, hi);
+            mv16<64, 96>(L + OFF_V1, e, k1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
-            if (F16)
-                mv16<64, 64>(L + OFF_V2, k1, k2, i, hi);
-            else
-                mv_fwd<64, 64>(L + OFF_V2, k1, k2, i, hi);
+            mv16<64, 64>(L + OFF_V2, k1, k2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) k2[r] = fmaxf(k2[r], 0.f);
 #pragma unroll
@@ -133,16 +127,10 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
             gq[2] = tz;
         } else if (__any(any)) {
             float h1[32], h2[32];
-            if (F16)
-                mv16<64, 32>(L + OFF_W1, f, h1, i, hi);
-            else
-                mv_fwd<64, 32>(L + OFF_W1, f, h1, i, hi);
+            mv16<64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            if (F16)
-                mv16<64, 64>(L + OFF_W2, h1, h2, i, hi);
-            else
-                mv_fwd<64, 64>(L + OFF_W2, h1, h2, i, hi);
+            mv16<64, 64>(L + OFF_W2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
             s0 = dot_lds<64>(L + OFF_W3, h2, hi);
@@ -155,16 +143,10 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
                 }
-                if (F16)
-                    mv16<64, 64>(L + OFF_W2T, a2, a1, i, hi);
-                else
-                    mv_bwd<64, 64>(L + OFF_W2, a2, a1, i, hi);
+                mv16<64, 64>(L + OFF_W2T, a2, a1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-                if (F16)
-                    mv16<32, 64>(L + OFF_W1T, a1, q, i, hi);
-                else
-                    mv_bwd<32, 64>(L + OFF_W1, a1, q, i, hi);
+                mv16<32, 64>(L + OFF_W1T, a1, q, i, hi);
                 float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -197,12 +179,30 @@ struct QueryParams {
     float* out_feat;
 };
 
+// weight images of the forward decode kernels: split-fp16 (tt_mfma16.h), W1^T / W2^T only when normals are asked for
 template <bool NEED_N, bool NEED_TEX>
-__global__ __launch_bounds__(256, 2) void k_query_points(QueryParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_W_FLOATS];
-    MlpPtrs w = p.w;
-    lds_load_geo_weights(L, w);
-    if (NEED_TEX) lds_load_tex_weights(L, w);
+__device__ __forceinline__ void stage_decode_images(float* L, const MlpPtrs& w) {
+    stage_image16<64, 32, false>(L + OFF_W1, w.w1, 32);
+    stage_image16<64, 64, false>(L + OFF_W2, w.w2, 64);
+    lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
+    if (NEED_N) {
+        stage_image16<32, 64, true>(L + OFF_W1T, w.w1, 32);
+        stage_image16<64, 64, true>(L + OFF_W2T, w.w2, 64);
+    }
+    if (NEED_TEX) {
+        stage_image16<64, 96, false>(L + OFF_V1, w.v1, 96);
+        stage_image16<64, 64, false>(L + OFF_V2, w.v2, 64);
+        lds_load_matrix(L + OFF_V3, w.v3, 3, 64, 64);
+    }
+}
+
+// 8 waves (2 per SIMD) share one set of split-fp16 weight images (93 KB: one workgroup per CU)
+#define DECODE_THREADS 512
+
+template <bool NEED_N, bool NEED_TEX>
+__global__ __launch_bounds__(DECODE_THREADS) void k_query_points(QueryParams p) {
+    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS];
+    stage_decode_images<NEED_N, NEED_TEX>(L, p.w);
     __syncthreads();
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const long long tiles_per_batch = (p.n_points + TT_TILE - 1) / TT_TILE;
@@ -268,11 +268,13 @@ struct QueryFieldParams {
 
 __global__ __launch_bounds__(256, 2) void k_query_field(QueryFieldParams p) {
     __shared__ __attribute__((aligned(16))) float L[LDS_FIELD_FLOATS];
-    {
+    {  // split-fp16 images (tt_mfma16.h), same footprint as the fp32 ones
         MlpPtrs w = p.w;
-        lds_load_geo_weights(L, w);
-        lds_load_matrix(L + OFF_D1, w.v1, 64, 32, W1S);
-        lds_load_matrix(L + OFF_D2, w.v2, 64, 64, W2S);
+        stage_image16<64, 32, false>(L + OFF_W1, w.w1, 32);
+        stage_image16<64, 64, false>(L + OFF_W2, w.w2, 64);
+        lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
+        stage_image16<64, 32, false>(L + OFF_D1, w.v1, 32);
+        stage_image16<64, 64, false>(L + OFF_D2, w.v2, 64);
         lds_load_matrix(L + OFF_D3, w.v3, 3, 64, 64);
     }
     __syncthreads();
@@ -296,17 +298,17 @@ __global__ __launch_bounds__(256, 2) void k_query_field(QueryFieldParams p) {
         float s0 = 0.f, d[3] = {0.f, 0.f, 0.f};
         if (any) {  // exact skip otherwise: bias-free MLPs of a zero vector
             float h1[32], h2[32];
-            mv_fwd<64, 32>(L + OFF_W1, f, h1, i, hi);
+            mv16<64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mv_fwd<64, 64>(L + OFF_W2, h1, h2, i, hi);
+            mv16<64, 64>(L + OFF_W2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
             s0 = dot_lds<64>(L + OFF_W3, h2, hi);
-            mv_fwd<64, 32>(L + OFF_D1, f, h1, i, hi);
+            mv16<64, 32>(L + OFF_D1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mv_fwd<64, 64>(L + OFF_D2, h1, h2, i, hi);
+            mv16<64, 64>(L + OFF_D2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
 #pragma unroll
@@ -342,26 +344,10 @@ struct DecodeRaysParams {
     float* features;
 };
 
-// 8 waves (2 per SIMD) share one set of split-fp16 weight images (93 KB: one workgroup per CU)
-#define DECODE_THREADS 512
 template <bool NEED_N, bool NEED_TEX>
 __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams p) {
     __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS];
-    {
-        MlpPtrs w = p.w;
-        stage_image16<64, 32, false>(L + OFF_W1, w.w1, 32);
-        stage_image16<64, 64, false>(L + OFF_W2, w.w2, 64);
-        lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
-        if (NEED_N) {
-            stage_image16<32, 64, true>(L + OFF_W1T, w.w1, 32);
-            stage_image16<64, 64, true>(L + OFF_W2T, w.w2, 64);
-        }
-        if (NEED_TEX) {
-            stage_image16<64, 96, false>(L + OFF_V1, w.v1, 96);
-            stage_image16<64, 64, false>(L + OFF_V2, w.v2, 64);
-            lds_load_matrix(L + OFF_V3, w.v3, 3, 64, 64);
-        }
-    }
+    stage_decode_images<NEED_N, NEED_TEX>(L, p.w);
     __syncthreads();
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
@@ -400,7 +386,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
             float tm, px, py, pz;
             sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
             float s0, gq[3], c[3];
-            decode_fwd<NEED_N, NEED_TEX, true>(L, dc, px, py, pz, rvalid, i, hi, s0, gq, c);
+            decode_fwd<NEED_N, NEED_TEX>(L, dc, px, py, pz, rvalid, i, hi, s0, gq, c);
             float nrm;
             const float sdf = s0 + sphere_bias(px, py, pz, cfg.sdf_bias_radius, nrm);
             if (rvalid && hi == 0 && !(cfg.flags & TT_DBG_NO_STORE)) {
@@ -484,9 +470,9 @@ extern "C" int tt_query_points(const float* packed, const tt_mlp_weights* w, con
     int cus = tt_num_cus();
     if (cus <= 0) return TT_ERR_DEVICE;
     long long n_tiles = ((n_points + TT_TILE - 1) / TT_TILE) * n_batch;
-    long long blocks = (n_tiles + 3) / 4;
-    if (blocks > 2LL * cus) blocks = 2LL * cus;
-    dim3 grid((unsigned)blocks), block(256);
+    long long blocks = (n_tiles + 7) / 8;
+    if (blocks > cus) blocks = cus;
+    dim3 grid((unsigned)blocks), block(DECODE_THREADS);
     hipStream_t s = (hipStream_t)stream;
     if (need_n && need_t)
         hipLaunchKernelGGL((k_query_points<true, true>), grid, block, 0, s, p);
