@@ -12,6 +12,8 @@ import triplaneturbo_amd as tt  # noqa: E402
 from triplaneturbo_amd import ops, synthetic  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+NV = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 g = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
@@ -23,9 +25,9 @@ r = tt.find("patch-renderer")({"patch_size": 40, "global_downsample": 3,
                               background=tt.find("solid-color-background")({})).to(dev)
 r.train()
 gen = torch.Generator().manual_seed(1)
-cache = (torch.randn(2, 6, 32, 256, 256, generator=gen) * 0.5).to(dev).requires_grad_(True)
-ro, rd, c2w, cd = synthetic.make_cameras(8, 128, 128)
-kw = dict(space_cache=cache, text_embed=torch.zeros(2, 77, 1024), camera_distances=cd.to(dev), c2w=c2w.to(dev))
+cache = (torch.randn(P, 6, 32, 256, 256, generator=gen) * 0.5).to(dev).requires_grad_(True)
+ro, rd, c2w, cd = synthetic.make_cameras(P * NV, 128, 128)
+kw = dict(space_cache=cache, text_embed=torch.zeros(P, 77, 1024), camera_distances=cd.to(dev), c2w=c2w.to(dev))
 ro, rd = ro.to(dev), rd.to(dev)
 bg = torch.ones(3, device=dev)
 
@@ -54,5 +56,5 @@ for _ in range(steps):
 torch.cuda.synchronize()
 ops.set_kernel_timer(None)
 per_step = {k: round(v[0] * v[1] / steps, 3) for k, v in t.summary().items()}  # avg ms x launches / steps
-print(f"training shapes: wall {wall:.2f} ms/step; HIP entry points (ms/step): {per_step} sum "
+print(f"training shapes ({P} prompts x {NV} views): wall {wall:.2f} ms/step; HIP entry points (ms/step): {per_step} sum "
       f"{sum(per_step.values()):.2f}", flush=True)
