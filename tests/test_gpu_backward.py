@@ -174,6 +174,32 @@ def test_sparse_rays_take_the_direct_scatter_path(mods, sb, copies, monkeypatch)
     _check(g_hip, g32, g64)
 
 
+def test_weight_matrices_of_any_scale(mods):
+    """The split-fp16 matrix products normalise each weight matrix (per matrix) and each sample's activations (per
+    sample) by powers of two, so weights far outside fp16's range must work: W1 x 3e5 (> 65504), W2 x 2e-6, etc."""
+    ops, functional = mods
+    P, R, n_view, Hh, Ww, S, seed = 1, 32, 1, 6, 6, 20, 44
+    g = torch.Generator().manual_seed(seed)
+    cache = torch.randn(P, 6, 32, R, R, generator=g) * 0.5
+    sw = O.init_mlp_weights([32, 64, 64, 1], g)
+    fw = O.init_mlp_weights([96, 64, 64, 3], g)
+    sw = [sw[0] * 3e5, sw[1] * 2e-6, sw[2] * 1.5]
+    fw = [fw[0] * 1e-5, fw[1] * 7e4, fw[2] * 1.2]
+    ro, rd, c2w, cd = O.make_cameras(P * n_view, Hh, Ww)
+    ts, te = O.uniform_intervals(P * n_view * Hh * Ww, S, 0.3, 3.2)
+    bg = torch.ones(3)
+    proj = {n: torch.randn(P * n_view, Hh, Ww, c, generator=g) for n, c in KEYS}
+    rck = dict(inv_std=40.0, rgb_grad_shrink=1.0, cos_anneal_ratio=1.0)
+    out, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    o32, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    o64, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    for key in ("comp_rgb", "opacity", "depth", "weights", "sdf", "features"):
+        e_hip = (out[key].detach().cpu().double() - o64[key].detach()).abs().max().item()
+        e_cpu = (o32[key].detach().double() - o64[key].detach()).abs().max().item()
+        assert e_hip <= max(4 * e_cpu, 2e-5), (key, e_hip, e_cpu)
+    _check(g_hip, g32, g64)
+
+
 def test_backward_is_linear_in_rays(mods):
     """Size-independent property used at full size: d loss/d(planes, weights) of a sum over rays equals the sum of
     the per-chunk gradients (the kernels accumulate with atomics; nothing may be dropped or double counted)."""

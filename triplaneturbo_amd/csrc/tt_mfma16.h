@@ -34,14 +34,29 @@ __device__ __forceinline__ void split16(float v, half_t& hi, half_t& lo) {
 }
 
 // Builds the image of M (ROWS x K).  src is row-major: M[R][c] = src[R * ld + c], or, with TRANSPOSED, the image of
-// src^T: M[R][c] = src[c * ld + R].  All threads of the workgroup take part; caller synchronises.
+// src^T: M[R][c] = src[c * ld + R].  The matrix is first normalised by the power of two that brings its largest
+// |entry| into [0.5, 1) (exact; any weight scale, from 1e-30 to 1e30, then splits with full precision and nothing can
+// overflow fp16); the inverse factor is stored in the first pad float of EVERY row (so row slices of an image carry
+// it) and mv16 folds it into its result scaling.  All threads of the workgroup must call this (it synchronises).
 template <int ROWS, int K, bool TRANSPOSED>
 __device__ __forceinline__ void stage_image16(float* dst_f, const float* __restrict__ src, int ld) {
     half_t* dst = reinterpret_cast<half_t*>(dst_f);
     constexpr int RS = 2 * K + 8;
+    unsigned* slot = reinterpret_cast<unsigned*>(dst_f + K);  // pad of row 0: max |entry| as bits, then the factor
+    if (threadIdx.x == 0) *slot = 0u;
+    __syncthreads();
+    float m = 0.f;
+    for (int e = threadIdx.x; e < ROWS * K; e += blockDim.x) m = fmaxf(m, __builtin_fabsf(src[e]));
+    atomicMax(slot, __builtin_bit_cast(unsigned, m));  // non-negative floats order like their bit patterns
+    __syncthreads();
+    int E = (int)(*slot >> 23);
+    E = E < 12 ? 12 : (E > 240 ? 240 : E);
+    const float sc = __builtin_bit_cast(float, (unsigned)(253 - E) << 23);  // 2^(126 - e)
+    const float un = __builtin_bit_cast(float, (unsigned)(E + 1) << 23);    // 1 / sc
+    __syncthreads();
     for (int e = threadIdx.x; e < ROWS * K; e += blockDim.x) {
         const int R = e / K, c = e - R * K;
-        const float v = TRANSPOSED ? src[(size_t)c * ld + R] : src[(size_t)R * ld + c];
+        const float v = (TRANSPOSED ? src[(size_t)c * ld + R] : src[(size_t)R * ld + c]) * sc;
         half_t hi, lo;
         split16(v, hi, lo);
         // element c = 16 s + (j&3) + 8 (j>>2) + 4 h
@@ -51,6 +66,7 @@ __device__ __forceinline__ void stage_image16(float* dst_f, const float* __restr
         p[0] = hi;   // term 0
         p[16] = lo;  // term 1: +2 half-wave blocks of 8 halfs
     }
+    for (int R = threadIdx.x; R < ROWS; R += blockDim.x) dst_f[(size_t)R * (K + 4) + K] = un;
 }
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
@@ -65,7 +81,8 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
                                      int hi) {
     constexpr int MT = NOUT / 32, KS = NIN / 16, RS = 2 * NIN + 8;
     const half_t* row = reinterpret_cast<const half_t*>(img_f) + (size_t)i * RS + 8 * hi;
-    float sc = 1.f, sc2048 = 2048.f, un = 1.f, un2048 = 1.f / 2048.f;
+    const float wun = img_f[(size_t)i * (NIN + 4) + NIN];  // inverse of the matrix normalisation (stage_image16)
+    float sc = 1.f, sc2048 = 2048.f, un = wun, un2048 = wun * (1.f / 2048.f);
     if (SCALED) {
         float m = 0.f;
 #pragma unroll
@@ -75,8 +92,8 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
         E = E < 12 ? 12 : (E > 240 ? 240 : E);                 // keeps all four factors normal
         sc = __builtin_bit_cast(float, (unsigned)(253 - E) << 23);         // 2^(126 - e): max |x| -> [0.5, 1)
         sc2048 = __builtin_bit_cast(float, (unsigned)(264 - E) << 23);     // sc * 2^11
-        un = __builtin_bit_cast(float, (unsigned)(E + 1) << 23);           // 1 / sc
-        un2048 = __builtin_bit_cast(float, (unsigned)(E - 10) << 23);      // 1 / (sc * 2^11)
+        un = wun * __builtin_bit_cast(float, (unsigned)(E + 1) << 23);        // 1 / sc
+        un2048 = wun * __builtin_bit_cast(float, (unsigned)(E - 10) << 23);   // 1 / (sc * 2^11)
     }
     f32x16 acc_h[MT], acc_l[MT];
 #pragma unroll
@@ -116,9 +133,6 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            if (SCALED)
-                y[16 * m + k] = __builtin_fmaf(acc_l[m][k], un2048, acc_h[m][k] * un);
-            else
-                y[16 * m + k] = __builtin_fmaf(acc_l[m][k], 1.f / 2048.f, acc_h[m][k]);
+            y[16 * m + k] = __builtin_fmaf(acc_l[m][k], un2048, acc_h[m][k] * un);
         }
 }
