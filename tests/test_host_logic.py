@@ -105,6 +105,29 @@ def test_world_to_camera_rotation_is_the_block_of_the_full_inverse():
     torch.testing.assert_close(functional._rot_world_to_cam(c2w), torch.inverse(c2w)[:, :3, :3], rtol=1e-5, atol=1e-6)
 
 
+def test_reference_training_yaml_loads_into_the_plugins():
+    """Drop-in check at the config level: the reference's own training config (configs/TriplaneTurbo_v1.yaml) must
+    instantiate our geometry / material / background / patch renderer with every key it sets (unknown keys raise).
+    Reads /root/reference, so it only runs in the build container (skipped on the GPU box)."""
+    path = "/root/reference/configs/TriplaneTurbo_v1.yaml"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    import yaml
+    txt = re.sub(r"\$\{[^}]*\}", "1", open(path).read())  # OmegaConf interpolations -> a plain scalar
+    s = yaml.safe_load(txt)["system"]
+    g = tt.find(s["geometry_type"])(s["geometry"])
+    m = tt.find(s["material_type"])(s["material"])
+    b = tt.find(s["background_type"])(s["background"])
+    r = tt.find(s["renderer_2nd_type"])(s["renderer_2nd"], geometry=g, material=m, background=b)
+    base = r.base_renderer
+    assert type(base).__name__ == "GenerativeSpaceSDFVolumeRenderer" and base.cfg.estimator == "importance"
+    assert (base.cfg.num_samples_per_ray, base.cfg.num_samples_per_ray_importance) == (64, 128)
+    assert r.cfg.patch_size == 40 and r.cfg.global_downsample == 3
+    assert abs(float(base.variance.inv_std) - 100.0) < 0.1  # exp(10 * 0.4605)
+    assert b.cfg.color_activation == "sigmoid-mipnerf" and b.encoding.n_output_dims == 16
+    assert g.cfg.isosurface_deformable_grid and hasattr(g, "deformation_network")
+
+
 def test_hashgrid_table_size_matches_oracle_levels():
     """tt_hashgrid_n_params is a host-only function: per-level sizes follow tcnn's rule restated in the oracle."""
     lib = _lib.load()
