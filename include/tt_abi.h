@@ -104,8 +104,8 @@ typedef struct {
     int32_t flags;             /* TT_R_* */
     int32_t image_w;           /* rays of a view form an image_w x (rays_per_view/image_w) image (pixel-block tiles);
                                   0 = unknown: tiles are runs of consecutive rays */
-    int32_t tile_sb;           /* consecutive samples of one ray per 32-sample tile: 1, 2, 4, ... 32; 0 = default (1).
-                                  1 suits evenly spaced samples; 4 suits importance sampling, where consecutive samples
+    int32_t tile_sb;           /* consecutive samples of one ray per 32-sample tile: 1, 2, 4, ... 32; 0 = default (2).
+                                  1-2 suit evenly spaced samples; 8 suits importance sampling, where consecutive samples
                                   of a ray share texels and are then combined inside the tile (performance only:
                                   results do not depend on it beyond fp32 summation order) */
     int32_t grad_copies;       /* backward: grad_packed holds this many privatised copies (copies,P,6,H,W,32), each

@@ -507,7 +507,8 @@ long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom*
     g->bpr = g->bpv = 0;
     int sb = cfg->tile_sb;
     if (const char* e = getenv("TT_SB")) sb = atoi(e);  // tuning only
-    if (!(sb == 1 || sb == 2 || sb == 4 || sb == 8 || sb == 16 || sb == 32)) sb = 1;
+    // 0 = auto: 4x4 pixels x 2 samples (measured at the bench shapes: backward 10.1 ms vs 10.5 at sb = 1, 11.8 at 4)
+    if (!(sb == 1 || sb == 2 || sb == 4 || sb == 8 || sb == 16 || sb == 32)) sb = 2;
     while (sb > 1 && sb > cfg->n_samples) sb /= 2;
     g->sb = sb;
     static const int BW[6] = {8, 4, 4, 2, 2, 1}, BH[6] = {4, 4, 2, 2, 1, 1};
