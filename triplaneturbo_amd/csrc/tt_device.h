@@ -495,59 +495,4 @@ __device__ __forceinline__ long long tile_ray(const TileGeom& g, long long b, in
     return rvalid ? ray : g.n_rays - 1;
 }
 
-// ---- tile layout and segmented wave scans -----------------------------------------------------------------
-// A 32-sample tile is RB rays x SB consecutive samples (RB*SB = 32).  Lane j = lane&31: ray rl = j / SB,
-// sample k = j % SB, so the SB samples of one ray sit in adjacent lanes and every scan below runs on
-// segments of SB lanes (width-SB shuffles).  SB = 32: one ray per tile; SB = 1: 32 adjacent rays marching in
-// lock-step (no scan at all).  Both half-waves run the same scans redundantly.
-template <int SB>
-__device__ __forceinline__ float seg_sum(float v) {
-#pragma unroll
-    for (int d = 1; d < SB; d <<= 1) v += __shfl_xor(v, d);
-    return v;
-}
-
-// exclusive prefix product over the SB lanes of a segment; total = product over the segment
-template <int SB>
-__device__ __forceinline__ float seg_excl_prod(float v, int k, float& total) {
-    if (SB == 1) {
-        total = v;
-        return 1.f;
-    }
-    float inc = v;
-#pragma unroll
-    for (int d = 1; d < SB; d <<= 1) {
-        float o = __shfl_up(inc, d, SB);
-        if (k >= d) inc *= o;
-    }
-    total = __shfl(inc, SB - 1, SB);
-    float ex = __shfl_up(inc, 1, SB);
-    return k == 0 ? 1.f : ex;
-}
-
-// Reverse affine scan for the backward of the transmittance product.  Per lane phi_k(x) = A x + B with
-// A = 1 - alpha_k, B = V_k alpha_k.  Returns R_{k+1} = (phi_{k+1} o ... o phi_{SB-1})(carry) for this lane and
-// updates carry to R_0 = (phi_0 o ... )(carry) of the segment.
-template <int SB>
-__device__ __forceinline__ float seg_rev_affine(float A_, float B_, int k, float& carry) {
-    if (SB == 1) {
-        const float rn = carry;
-        carry = fmaf(A_, carry, B_);
-        return rn;
-    }
-#pragma unroll
-    for (int d = 1; d < SB; d <<= 1) {
-        const float Ao = __shfl_down(A_, d, SB), Bo = __shfl_down(B_, d, SB);
-        if (k + d < SB) {
-            B_ = fmaf(A_, Bo, B_);
-            A_ *= Ao;
-        }
-    }
-    const float Ri = fmaf(A_, carry, B_);
-    float Rnext = __shfl_down(Ri, 1, SB);
-    if (k == SB - 1) Rnext = carry;
-    carry = __shfl(Ri, 0, SB);
-    return Rnext;
-}
-
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }

@@ -2,7 +2,10 @@
 // backward.  Both kernels touch ~10 floats per sample and are bandwidth-bound; the expensive per-sample
 // decode (plane gather + MLPs) lives in tt_decode.hip / tt_backward.hip and is decoupled from ray order.
 //
-// One wave per ray, lane <-> sample (64 samples per pass, coalesced [ray][sample] rows).
+// One wave per ray, lane <-> sample (64 samples per pass, coalesced [ray][sample] rows); scans and reductions on DPP
+// modifiers, divisions as reciprocal-multiplies, the logistic on the hardware exp2: with library expf, IEEE
+// divisions and ds_bpermute shuffles these kernels were instruction-bound (42.7 M VALU instructions per forward launch
+// = 80 us of issue) rather than bandwidth-bound.
 //   forward : alpha_i (neus_volume_renderer.py:93-117), T_i = prod_{j<i}(1-alpha_j), w_i = alpha_i T_i
 //             (nerfacc.render_weight_from_alpha), opacity/depth/rgb/normal sums and z_variance
 //             (nerfacc.accumulate_along_rays x5, renderer :414-431,467-472).
@@ -36,6 +39,12 @@ struct AlphaTerms {
     bool pass;
 };
 
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }  // 1 ulp
+// logistic function on the hardware exp2 / rcp (2 + 2 instructions instead of ~25 for 1 / (1 + expf(-x)) with the
+// IEEE division): relative error ~|x| 2^-24 from the rounded x log2(e), i.e. <= 1e-6 wherever the result is not
+// saturated; overflow of exp2 for x < -88 gives rcp(inf) = 0 like the reference
+__device__ __forceinline__ float sigmoid_(float x) { return rcp_(1.f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
+
 // neus_volume_renderer.py:98-116 (use_volsdf = False)
 __device__ __forceinline__ AlphaTerms neus_alpha_terms(float sdf, float cosv, float dt, float kstd, float ratio) {
     AlphaTerms a;
@@ -44,20 +53,75 @@ __device__ __forceinline__ AlphaTerms neus_alpha_terms(float sdf, float cosv, fl
     a.dic_dcos = (c1 > 0.f ? 0.5f * (1.f - ratio) : 0.f) + (c2 > 0.f ? ratio : 0.f);
     a.half = dt * 0.5f;
     const float next_sdf = sdf + ic * a.half, prev_sdf = sdf - ic * a.half;
-    a.sA = sigmoidf_(prev_sdf * kstd);
-    a.sB = sigmoidf_(next_sdf * kstd);
+    a.sA = sigmoid_(prev_sdf * kstd);
+    a.sB = sigmoid_(next_sdf * kstd);
     a.den = a.sA + 1e-5f;
-    a.rat = ((a.sA - a.sB) + 1e-5f) / a.den;
+    a.rat = ((a.sA - a.sB) + 1e-5f) * rcp_(a.den);
     a.alpha = fminf(fmaxf(a.rat, 0.f), 1.f);
     a.pass = a.rat >= 0.f && a.rat <= 1.f;
     return a;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-    return v;
+// ---- cross-lane primitives on DPP (VALU data-parallel-primitive modifiers: no LDS traffic, ~1 instruction per step;
+// the ds_bpermute shuffles they replace made these bandwidth-bound kernels instruction-bound) ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity),
+                                                                 __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf,
+                                                                 false));
 }
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_BCAST15 0x142  // lane 15 of every row -> the next row (enable rows 1, 3: mask 0xa)
+#define DPP_BCAST31 0x143  // lane 31 -> rows 2, 3 (mask 0xc)
+#define DPP_WAVE_SHR1 0x138
+
+// sum over the 64 lanes, wave-uniform
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<DPP_ROW_SHR(1), 0xf>(0.f, v);
+    v += dpp_f<DPP_ROW_SHR(2), 0xf>(0.f, v);
+    v += dpp_f<DPP_ROW_SHR(4), 0xf>(0.f, v);
+    v += dpp_f<DPP_ROW_SHR(8), 0xf>(0.f, v);
+    v += dpp_f<DPP_BCAST15, 0xa>(0.f, v);
+    v += dpp_f<DPP_BCAST31, 0xc>(0.f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// exclusive prefix product over the 64 lanes (lane 0 gets 1); total = product of all lanes (wave-uniform)
+__device__ __forceinline__ float wave_excl_prod(float v, float& total) {
+    v *= dpp_f<DPP_ROW_SHR(1), 0xf>(1.f, v);
+    v *= dpp_f<DPP_ROW_SHR(2), 0xf>(1.f, v);
+    v *= dpp_f<DPP_ROW_SHR(4), 0xf>(1.f, v);
+    v *= dpp_f<DPP_ROW_SHR(8), 0xf>(1.f, v);  // inclusive within each row of 16
+    v *= dpp_f<DPP_BCAST15, 0xa>(1.f, v);
+    v *= dpp_f<DPP_BCAST31, 0xc>(1.f, v);  // inclusive over the wave
+    total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return dpp_f<DPP_WAVE_SHR1, 0xf>(1.f, v);  // shift right by one lane: exclusive
+}
+
+// Affine recurrence R_l = A_l R_{l-1} + B_l over the lanes, R_{-1} = carry (the backward maps lane l to the sample
+// 63 - l of a pass, so that the suffix recurrence over samples is this prefix recurrence over lanes).  Returns
+// R_{l-1} for this lane and updates carry to R_63.  Inclusive scan of the maps by composition
+// (A, B)_l o (A, B)_seg = (A_l A_seg, A_l B_seg + B_l), then one lane shift.
+__device__ __forceinline__ float wave_affine_prev(float A, float B, float& carry) {
+#define AFF_STEP(CTRL, MASK)                                   \
+    {                                                          \
+        const float As = dpp_f<CTRL, MASK>(1.f, A), Bs = dpp_f<CTRL, MASK>(0.f, B); \
+        B = fmaf(A, Bs, B);                                    \
+        A *= As;                                               \
+    }
+    AFF_STEP(DPP_ROW_SHR(1), 0xf)
+    AFF_STEP(DPP_ROW_SHR(2), 0xf)
+    AFF_STEP(DPP_ROW_SHR(4), 0xf)
+    AFF_STEP(DPP_ROW_SHR(8), 0xf)
+    AFF_STEP(DPP_BCAST15, 0xa)
+    AFF_STEP(DPP_BCAST31, 0xc)
+#undef AFF_STEP
+    const float R = fmaf(A, carry, B);                       // R_l
+    const float prev = dpp_f<DPP_WAVE_SHR1, 0xf>(carry, R);  // R_{l-1}; lane 0 gets the carry
+    carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, R), 63));
+    return prev;
+}
+
 
 struct FwdIn {
     float ts, te, sdf, gx, gy, gz, f0, f1, f2;
@@ -83,17 +147,18 @@ __device__ __forceinline__ void march_pass_fwd(const MarchFwdParams& p, const Fw
                                                float dy, float dz, FwdAcc& a, float& wgt, float& Ti, float& tm) {
     tm = (v.ts + v.te) / 2.f;
     const float gn = fmaxf(sqrtf(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz), 1e-12f);  // F.normalize eps
-    const float nx = v.gx / gn, ny = v.gy / gn, nz = v.gz / gn;
+    const float ign = rcp_(gn);
+    const float nx = v.gx * ign, ny = v.gy * ign, nz = v.gz * ign;
     const float cosv = dx * nx + dy * ny + dz * nz;
     float alpha = neus_alpha_terms(v.sdf, cosv, v.te - v.ts, p.inv_std, p.ratio).alpha;
     if (!valid) alpha = 0.f;
     float total;
-    Ti = a.T * seg_excl_prod<64>(1.f - alpha, lane, total);
+    Ti = a.T * wave_excl_prod(1.f - alpha, total);
     a.T *= total;
     wgt = alpha * Ti;
     // NoMaterial + sigmoid-mipnerf (no_material.py:41-54, ops.py:118-119)
-    const float r = sigmoidf_(v.f0) * 1.002f - 0.001f, g = sigmoidf_(v.f1) * 1.002f - 0.001f,
-                b = sigmoidf_(v.f2) * 1.002f - 0.001f;
+    const float r = sigmoid_(v.f0) * 1.002f - 0.001f, g = sigmoid_(v.f1) * 1.002f - 0.001f,
+                b = sigmoid_(v.f2) * 1.002f - 0.001f;
     a.op += wgt;
     a.d = fmaf(wgt, tm, a.d);
     a.r = fmaf(wgt, r, a.r);
@@ -245,14 +310,15 @@ __device__ __forceinline__ f32x4 march_pass_bwd(const MarchBwdParams& p, const B
     const float tm = (v.ts + v.te) / 2.f;
     const float gn_raw = sqrtf(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz);
     const float gn = fmaxf(gn_raw, 1e-12f);
-    const float nx = v.gx / gn, ny = v.gy / gn, nz = v.gz / gn;
+    const float ign = rcp_(gn);
+    const float nx = v.gx * ign, ny = v.gy * ign, nz = v.gz * ign;
     const float cosv = rb.dx * nx + rb.dy * ny + rb.dz * nz;
     const AlphaTerms a = neus_alpha_terms(v.sdf, cosv, v.te - v.ts, kstd, p.ratio);
     const float alpha = valid ? a.alpha : 0.f;
     const float Ti = valid ? v.trans : 0.f;
     const float wgt = alpha * Ti;
-    const float rr = sigmoidf_(v.f0) * 1.002f - 0.001f, rg = sigmoidf_(v.f1) * 1.002f - 0.001f,
-                rbl = sigmoidf_(v.f2) * 1.002f - 0.001f;
+    const float rr = sigmoid_(v.f0) * 1.002f - 0.001f, rg = sigmoid_(v.f1) * 1.002f - 0.001f,
+                rbl = sigmoid_(v.f2) * 1.002f - 0.001f;
     // dL/dw_i (z_variance = sum w (t-D)^2 with D = sum w t)
     const float dd = tm - rb.D;
     float V = rb.b_op + rb.b_d * tm + rb.b_z * (dd * dd - 2.f * tm * rb.D * (1.f - rb.op)) +
@@ -260,10 +326,12 @@ __device__ __forceinline__ f32x4 march_pass_bwd(const MarchBwdParams& p, const B
     V += v.gw;
     if (!valid) V = 0.f;
     // R_i = V_i a_i + (1 - a_i) R_{i+1};  dL/d alpha_i = T_i (V_i - R_{i+1})
-    const float Rnext = seg_rev_affine<64>(1.f - alpha, V * alpha, lane, Rcarry);
+    // (lanes hold the samples of a pass in REVERSE order: the sample after this one sits in lane - 1)
+    const float Rnext = wave_affine_prev(1.f - alpha, V * alpha, Rcarry);
     const float dalpha = Ti * (V - Rnext);
     const float drat = (valid && a.pass) ? dalpha : 0.f;
-    const float dnum = drat / a.den, dden = -drat * a.rat / a.den;
+    const float iden = rcp_(a.den);
+    const float dnum = drat * iden, dden = -drat * a.rat * iden;
     const float dA = (dnum + dden) * a.sA * (1.f - a.sA) * kstd, dB = (-dnum) * a.sB * (1.f - a.sB) * kstd;
     const float sbar = dA + dB;
     const float dcos = a.half * (dB - dA) * a.dic_dcos;
@@ -272,13 +340,13 @@ __device__ __forceinline__ f32x4 march_pass_bwd(const MarchBwdParams& p, const B
     float gbx, gby, gbz;
     if (gn_raw > 1e-12f) {
         const float nd = nx * nbx + ny * nby + nz * nbz;
-        gbx = (nbx - nx * nd) / gn;
-        gby = (nby - ny * nd) / gn;
-        gbz = (nbz - nz * nd) / gn;
+        gbx = (nbx - nx * nd) * ign;
+        gby = (nby - ny * nd) * ign;
+        gbz = (nbz - nz * nd) * ign;
     } else {
-        gbx = nbx / 1e-12f;
-        gby = nby / 1e-12f;
-        gbz = nbz / 1e-12f;
+        gbx = nbx * 1e12f;
+        gby = nby * 1e12f;
+        gbz = nbz * 1e12f;
     }
     f32x4 o = {sbar + v.gs, gbx + v.ggx, gby + v.ggy, gbz + v.ggz};
     return o;
@@ -312,18 +380,18 @@ __global__ __launch_bounds__(256) void k_march_bwd(MarchBwdParams p) {
             BwdIn in[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
-                const int si = 64 * k + lane;
+                const int si = 64 * k + 63 - lane;  // reverse order inside a pass (see march_pass_bwd)
                 in[k] = march_load_bwd(p, ray * S + (si < S ? si : 0));
             }
 #pragma unroll
             for (int k = NP - 1; k >= 0; --k) {
-                const int si = 64 * k + lane;
+                const int si = 64 * k + 63 - lane;
                 const f32x4 o = march_pass_bwd(p, in[k], si < S, lane, rb, Rcarry);
                 if (si < S) *reinterpret_cast<f32x4*>(p.ws + (ray * S + si) * 4) = o;
             }
         } else {
             for (int base = ((S - 1) / 64) * 64; base >= 0; base -= 64) {
-                const int si = base + lane;
+                const int si = base + 63 - lane;
                 const bool valid = si < S;
                 const long long sidx = ray * S + (valid ? si : 0);
                 const BwdIn v = march_load_bwd(p, sidx);
