@@ -30,8 +30,17 @@ def find(name: str):
         main_name, sub_name = name.split(":")
         name_list = sub_name.split(",") if "," in sub_name else [sub_name]
         name_list.append(main_name)
-        return type(f"{main_name}.{sub_name}", tuple(__modules__[n] for n in name_list), {})
-    return __modules__[name]
+        return type(f"{main_name}.{sub_name}", tuple(_lookup(n) for n in name_list), {})
+    return _lookup(name)
+
+
+def _lookup(name: str):
+    try:
+        return __modules__[name]
+    except KeyError:
+        raise KeyError(f"{name!r} is not a triplaneturbo_amd plugin (this package rebuilds the volume-render hot path "
+                       f"only; registered: {sorted(__modules__)}).  Other threestudio modules stay with the reference: "
+                       f"register ours into threestudio's table instead (INTEGRATION.md)") from None
 
 
 def parse_structured(fields: Any, cfg: Optional[Any] = None) -> Any:
