@@ -234,8 +234,8 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "avg_kernel_ms": round(ksum[dom][0], 4),
                     "note": "algorithmic FLOP/sample x samples per launch over the HIP-event duration, against the "
-                            "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32), which is what the texture backward still "
-                            "uses; the forward and geometry-backward mat-vec chains run as 2-term split-fp16 MFMAs "
+                            "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32), which is what most of the texture "
+                            "backward still uses; the forward and geometry-backward mat-vec chains run as 2-term split-fp16 MFMAs "
                             "(22-bit products, fp32 accumulate, 3 MFMAs at 16x the fp32 rate), so their `tflops` in "
                             "`kernels` may exceed this peak"}
         # the bandwidth-bound stage: the ray march (k_march_fwd / k_march_bwd), re-timed on the live buffers of one
@@ -250,7 +250,8 @@ def main():
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "dtype_note": "fp32 storage, accumulation and element-wise math; matrix products of the "
-            "forward decode and the geometry backward as hi + lo/2048 fp16 splits (22 significand bits)",
+            "forward decode, the geometry backward and the first layer of the texture backward as hi + lo/2048 fp16 "
+            "splits (22 significand bits)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: per GPU 1 triplane (1,6,32,256,256), 1 view 256x256 rays, "
                                    "128 uniform samples on [0.1,4.0], fwd + bwd of the G6 loss "
