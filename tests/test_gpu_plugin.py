@@ -118,6 +118,27 @@ def test_patch_renderer_training_and_eval(dev):
     assert out["comp_rgb"].shape == (2, 24, 24, 3) and out["opacity"].shape == (2, 24, 24, 1)
     out["comp_rgb"].sum().backward()
     assert torch.isfinite(cache.grad).all() and cache.grad.abs().sum() > 0
+    # values: patch region = a direct render of the patch rays, the rest = the bilinearly upsampled global render
+    # (patch_renderer.py:49-89); sampling made deterministic so the three renders see the same intervals
+    p.base_renderer.randomized = False
+    torch.manual_seed(5)
+    with torch.no_grad():
+        out = p(ro.to(dev), rd.to(dev), None, torch.ones(3, device=dev), **kw)
+        torch.manual_seed(5)
+        px = torch.randint(0, 24 - 8, (1,)).item()
+        py = torch.randint(0, 24 - 8, (1,)).item()
+        direct = p.base_renderer(ro[:, py:py + 8, px:px + 8].contiguous().to(dev),
+                                 rd[:, py:py + 8, px:px + 8].contiguous().to(dev), None, torch.ones(3, device=dev), **kw)
+        F = torch.nn.functional
+        lo_o = F.interpolate(ro.permute(0, 3, 1, 2), (8, 8), mode="bilinear").permute(0, 2, 3, 1).contiguous()
+        lo_d = F.interpolate(rd.permute(0, 3, 1, 2), (8, 8), mode="bilinear").permute(0, 2, 3, 1).contiguous()
+        glob = p.base_renderer(lo_o.to(dev), lo_d.to(dev), None, torch.ones(3, device=dev), **kw)
+    for k in ("comp_rgb", "opacity", "depth", "comp_normal"):
+        torch.testing.assert_close(out[k][:, py:py + 8, px:px + 8], direct[k], rtol=1e-5, atol=1e-6)
+        up = F.interpolate(glob[k].permute(0, 3, 1, 2), (24, 24), mode="bilinear").permute(0, 2, 3, 1)
+        mask = torch.ones(24, 24, dtype=torch.bool, device=dev)
+        mask[py:py + 8, px:px + 8] = False
+        torch.testing.assert_close(out[k][:, mask], up[:, mask], rtol=1e-5, atol=1e-6)
     p.eval()
     with torch.no_grad():
         out = p(ro.to(dev), rd.to(dev), None, torch.ones(3, device=dev), **kw)

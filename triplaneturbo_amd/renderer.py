@@ -249,13 +249,26 @@ class PatchRenderer(BaseModule):
         eager = out.eager_keys() if hasattr(out, "eager_keys") else list(out)  # per-sample extras stay lazy
         valid = [k for k in eager if torch.is_tensor(out[k]) and out[k].ndim == out["comp_rgb"].ndim
                  and out[k][..., 0].shape == out["comp_rgb"][..., 0].shape]
+        grad_mode = torch.is_grad_enabled()
+        detach = self.cfg.global_detach
+
+        def composite(low: Tensor, patch: Tensor):
+            # bilinear upsample of the global render + paste of the patch (patch_renderer.py:74-88); evaluated when the
+            # key is first read: a loss reads a few of the ~10 image-shaped outputs, the reference upsamples all of them
+            def run():
+                with torch.set_grad_enabled(grad_mode):
+                    up = F.interpolate(low.permute(0, 3, 1, 2), (H, W), mode="bilinear").permute(0, 2, 3, 1)
+                    if detach:
+                        up = up.detach()
+                    up = up.clone()
+                    up[:, py:py + PS, px:px + PS] = patch
+                    return up
+            return run
+
+        if not isinstance(out_global, functional.LazyOutputs):
+            out_global = functional.LazyOutputs(out_global)
         for k in valid:
-            up = F.interpolate(out_global[k].permute(0, 3, 1, 2), (H, W), mode="bilinear").permute(0, 2, 3, 1)
-            if self.cfg.global_detach:
-                up = up.detach()
-            up = up.clone()
-            up[:, py:py + PS, px:px + PS] = out[k]
-            out_global[k] = up
+            out_global.set_lazy(k, composite(dict.__getitem__(out_global, k), out[k]))
         return out_global
 
     def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False) -> None:
