@@ -97,6 +97,7 @@ def test_backward_small_golden(mods, golden_dir):
     (1, 32, 1, 8, 8, 32, 1),     # one full tile per ray
     (2, 32, 2, 5, 7, 45, 2),     # 2 prompts x 2 views, ragged last tile, tex tiles straddling rays/prompts
     (1, 128, 1, 24, 24, 32, 3),  # BASELINE config[0] planes, reduced ray count (CPU double backward is slow)
+    (1, 40, 3, 9, 11, 19, 4),    # plane size not a power of two, 3 views of one prompt, odd sizes everywhere
 ])
 def test_backward_matches_oracle(mods, P, R, n_view, Hh, Ww, S, seed):
     g = torch.Generator().manual_seed(seed)

@@ -58,7 +58,7 @@ def test_query_points_matches_reference_golden(ops, golden_dir):
     torch.testing.assert_close(grad.cpu().view(B, N, 3), T(ref["g4_sdf_grad"]), rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("R,N", [(16, 33), (128, 5000), (256, 4096)])
+@pytest.mark.parametrize("R,N", [(16, 33), (48, 777), (128, 5000), (256, 4096)])  # 48: not a power of two
 def test_query_points_matches_oracle(ops, R, N):
     g = torch.Generator().manual_seed(R + N)
     P, n_view = 2, 2
