@@ -74,6 +74,11 @@ def _chk(t: Tensor, name: str, shape: Optional[Sequence[int]] = None) -> Tensor:
         raise RuntimeError(f"{name} must live on the GPU (triplaneturbo_amd has no CPU path)")
     if t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        # the kernels run on the current device's current stream (one process per GPU): a tensor of another GPU
+        # would be a wild pointer there
+        raise RuntimeError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           f"call torch.cuda.set_device (one process per GPU)")
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
     return t.contiguous()
