@@ -4,9 +4,10 @@
  * This is the drop-in boundary of triplaneturbo_amd.  Every entry point is plain C:
  * raw DEVICE pointers (fp32 unless noted), explicit sizes, a config struct, a hipStream_t
  * passed as void*.  The caller (PyTorch-ROCm host code, or any FFI) allocates every output
- * and workspace; the library itself keeps one 16 KB device scratch per GPU (work-queue counters of the per-sample
- * kernels: rotating slots so launches on different streams do not share counters, self-resetting so a launch can be
- * captured in a hipGraph; allocated at the first launch, which therefore must not be inside a capture); re-entrant; safe from one
+ * and workspace; the library itself keeps one 266 KB device scratch per GPU (work-queue counters of the per-sample
+ * kernels: one 64-byte slot per stream, zeroed on the stream in front of every launch, and a never-reused slot per
+ * launch recorded under stream capture, so a launch can be captured in a hipGraph; allocated at the first launch,
+ * which therefore must not be inside a capture); no environment variable is read; re-entrant; safe from one
  * host thread per device.  Return 0 on success, a negative tt_status on error (no C++
  * exceptions cross the boundary).  tt_strerror() maps codes to text.
  *
@@ -56,7 +57,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 8
+#define TT_ABI_VERSION 9
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -111,13 +112,19 @@ typedef struct {
     int32_t grad_copies;       /* backward: grad_packed holds this many privatised copies (copies,P,6,H,W,32), each
                                   workgroup scatters into one of them and tt_planes_unpack_grad sums them; spreads
                                   same-texel atomics.  0/1 = a single copy */
+    int32_t tile_chunk;        /* samples of a ray block per work item of the dynamic queue; 0 = automatic (performance
+                                  only, like tile_sb) */
 } tt_render_cfg;
 
 #define TT_R_PER_SAMPLE 1 /* also write per-sample sdf / sdf_grad / features (training extras, renderer :532-545) */
+#define TT_R_EXACT_F32 2  /* every matrix product on the fp32-input MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fmaf
+                             chain) instead of the default 2-term split-fp16 products (22-bit significands, fp32
+                             accumulation, ~5x less matrix-pipe time): the A/B reference of that scheme, and an opt-out */
 
-/* tt_query_points flags */
-#define TT_Q_NORMAL 1 /* output sdf_grad (analytic normal path) */
-#define TT_Q_TEX 2    /* output features (texture planes + feature net) */
+/* tt_query_points / tt_query_field / tt_decode_rays / tt_points_bwd_* flags */
+#define TT_Q_NORMAL 1    /* output sdf_grad (analytic normal path) */
+#define TT_Q_TEX 2       /* output features (texture planes + feature net) */
+#define TT_Q_EXACT_F32 4 /* as TT_R_EXACT_F32 */
 
 const char* tt_strerror(int status);
 int tt_abi_version(void);
@@ -141,10 +148,11 @@ int tt_query_points(const float* packed, const tt_mlp_weights* w, const float* p
 /* Implicit-field query for isosurface extraction (forward_field, few_step...:375-394; callers
  * generative_space_mesh_rasterize_renderer.py:428-452 and triplaneturbo_executable/utils/mesh_exporter.py:78-105):
  * sdf (n_batch*n_points) and deformation (n_batch*n_points,3) from the geometry planes only.
- * `w`: sdf net in w1..w3, DEFORMATION net (32->64->64->3, few_step...:113-122) in v1..v3. */
+ * `w`: sdf net in w1..w3, DEFORMATION net (32->64->64->3, few_step...:113-122) in v1..v3.  flags: TT_Q_EXACT_F32 or 0. */
 int tt_query_field(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
                    int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
-                   float radius, float sdf_bias_radius, float* out_sdf, float* out_deformation, void* stream);
+                   float radius, float sdf_bias_radius, int32_t flags, float* out_sdf, float* out_deformation,
+                   void* stream);
 
 /* Decode only, along rays: sdf [+ sdf_grad if TT_Q_NORMAL] [+ features if TT_Q_TEX] at the mid-points of the
  * intervals (n_rays,S).  The importance sampler's proposal pass (prop_sigma_fn, renderer :243-299) uses flags = 0. */
@@ -224,11 +232,11 @@ int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, const float*
  *       deformation head of tt_query_field (d/d U1 = the sum of the three 64x32 column blocks of grads->v1). */
 int tt_points_bwd_geo(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
                       int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
-                      float radius, float sdf_bias_radius, const float* g_sdf, const float* g_sdf_grad,
+                      float radius, float sdf_bias_radius, int32_t flags, const float* g_sdf, const float* g_sdf_grad,
                       float* workspace, float* grad_packed, const tt_mlp_grads* grads, void* stream);
 int tt_points_bwd_tex(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
                       int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
-                      float radius, int32_t plane_base, const float* g_features, float* grad_packed,
+                      float radius, int32_t plane_base, int32_t flags, const float* g_features, float* grad_packed,
                       const tt_mlp_grads* grads, void* stream);
 
 /* Multiresolution hash encoding of 3-D points in [0,1]^3 (tcnn "HashGrid", Linear interpolation, fp32).

@@ -120,11 +120,10 @@ def test_backward_matches_oracle(mods, P, R, n_view, Hh, Ww, S, seed):
 @pytest.mark.parametrize("chunk,blocked,sb", [(1, True, 1), (7, True, 1), (64, True, 1), (5, False, 1), (9, True, 2),
                                               (8, True, 4), (3, True, 8), (64, False, 4), (16, True, 16), (45, True, 32)])
 def test_every_tiling_matches_oracle(mods, chunk, blocked, sb, monkeypatch):
-    """The per-sample kernels tile the (ray, sample) space as 8x4-pixel ray blocks (or 32-ray strips when the image
-    width is unknown) x chunks of sample indices; TT_CHUNK forces the chunk length.  Every tiling must reproduce
-    the oracle (forward outputs and all gradients), incl. ragged image edges (5x7 rays) and ragged chunks."""
-    monkeypatch.setenv("TT_CHUNK", str(chunk))
-    monkeypatch.setenv("TT_SB", str(sb))  # tile = 32/sb adjacent rays x sb consecutive samples
+    """The per-sample kernels tile the (ray, sample) space as pixel blocks (or 32-ray strips when the image width is
+    unknown) x chunks of sample indices; cfg.tile_chunk forces the chunk length, cfg.tile_sb the tile shape
+    (32/sb adjacent rays x sb consecutive samples).  Every tiling must reproduce the oracle (forward outputs and all
+    gradients), incl. ragged image edges (5x7 rays) and ragged chunks."""
     ops, functional = mods
     P, R, n_view, Hh, Ww, S, seed = 2, 32, 2, 5, 7, 45, 21
     g = torch.Generator().manual_seed(seed)
@@ -140,7 +139,8 @@ def test_every_tiling_matches_oracle(mods, chunk, blocked, sb, monkeypatch):
     if not blocked:  # hide the image width from the kernels -> linear 32-ray strips
         orig = ops.render_samples
         monkeypatch.setattr(ops, "render_samples", lambda *a, image_w=0, **k: orig(*a, image_w=0, **k))
-    out, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    out, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj,
+                                   dict(rck, tile_sb=sb, tile_chunk=chunk))
     o32, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
     o64, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
     for key in ("comp_rgb", "opacity", "depth", "z_variance", "weights", "sdf", "features"):
@@ -155,7 +155,6 @@ def test_sparse_rays_take_the_direct_scatter_path(mods, sb, copies, monkeypatch)
     """Rays several texels apart (9x6 rays over 128x128 planes): a tile's footprint is far wider than the 8x8 slot
     window of the matrix-core combine, so most corner references lose their slot and go through the direct
     half-wave-per-reference scatter.  Also covers privatised gradient copies (cfg.grad_copies > 1)."""
-    monkeypatch.setenv("TT_SB", str(sb))
     ops, functional = mods
     P, R, n_view, Hh, Ww, S, seed = 1, 128, 2, 9, 6, 24, 33
     g = torch.Generator().manual_seed(seed)
@@ -169,7 +168,7 @@ def test_sparse_rays_take_the_direct_scatter_path(mods, sb, copies, monkeypatch)
     proj = {n: torch.randn(P * n_view, Hh, Ww, c, generator=g) for n, c in KEYS}
     rck = dict(inv_std=60.0, rgb_grad_shrink=1.0, cos_anneal_ratio=0.5)
     out, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj,
-                                   dict(rck, grad_copies=copies))
+                                   dict(rck, grad_copies=copies, tile_sb=sb))
     o32, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
     o64, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
     _check(g_hip, g32, g64)

@@ -174,7 +174,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == 8
+    assert lib.tt_abi_version() == 9
     assert b"bad argument" in lib.tt_strerror(-1)
 
 
@@ -186,7 +186,7 @@ def test_ctypes_struct_layout_matches_header(tmp_path):
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tt_render_cfg), offsetof(tt_render_cfg, n_rays),
          offsetof(tt_render_cfg, radius), offsetof(tt_render_cfg, flags), offsetof(tt_render_cfg, image_w),
-         offsetof(tt_render_cfg, grad_copies), sizeof(tt_mlp_weights), sizeof(tt_mlp_grads));
+         offsetof(tt_render_cfg, tile_chunk), sizeof(tt_mlp_weights), sizeof(tt_mlp_grads));
   return 0; }'''
     src = tmp_path / "t.c"
     src.write_text(code)
@@ -194,7 +194,7 @@ int main(void) {
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     c = _lib.RenderCfg
-    got = [ctypes.sizeof(c), c.n_rays.offset, c.radius.offset, c.flags.offset, c.image_w.offset, c.grad_copies.offset,
+    got = [ctypes.sizeof(c), c.n_rays.offset, c.radius.offset, c.flags.offset, c.image_w.offset, c.tile_chunk.offset,
            ctypes.sizeof(_lib.MlpWeights), ctypes.sizeof(_lib.MlpWeights)]
     assert [int(x) for x in out] == got
 
@@ -227,3 +227,26 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
                               null) == -1  # TT_Q_NORMAL without an sdf_grad buffer
     assert lib.tt_grid_sample_2d_grad2(one, one, one, one, one, 1, 4, 8, 8, 5, 1, 0, one, one, one, null) == -2
     assert b"unsupported" in lib.tt_strerror(-2)
+
+
+def test_product_library_never_reads_the_environment():
+    """The tuning / ablation hooks (TT_DEBUG_FLAGS, TT_SB, ...) exist only in the -DTT_TUNING dev build: the product
+    library must not import getenv at all."""
+    path = _lib.build()
+    out = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out
+
+
+def test_geometry_decode_applies_split_channels_v1():
+    """few_step...:187-196: geo planes keep the first C channels, tex planes the last C of the generator's 2C."""
+    from triplaneturbo_amd.geometry import StableDiffusionTriplaneDualAttention
+
+    class Gen(torch.nn.Module):
+        def forward_decode(self, latents):
+            return latents
+
+    g = StableDiffusionTriplaneDualAttention({}, space_generator=Gen())
+    x = torch.randn(2, 6, 64, 4, 4)
+    y = g.decode(x)
+    assert y.shape == (2, 6, 32, 4, 4)
+    assert torch.equal(y[:, :3], x[:, :3, :32]) and torch.equal(y[:, 3:], x[:, 3:, 32:])

@@ -2,6 +2,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+from triplaneturbo_amd import _lib
+_lib.use_tuning_build()  # -DTT_TUNING variant (honours TT_DEBUG_FLAGS)
 from triplaneturbo_amd import ops
 dev = torch.device("cuda", 0)
 inp = bench.make_inputs(0, dev)

@@ -7,6 +7,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+from triplaneturbo_amd import _lib  # noqa: E402
+
+_lib.use_tuning_build()  # the -DTT_TUNING variant: honours TT_DEBUG_FLAGS & co (the product library does not)
 from triplaneturbo_amd import functional, ops  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5

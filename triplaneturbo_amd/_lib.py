@@ -15,6 +15,9 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libtt_hip.so")
+# dev-only variant built with -DTT_TUNING: honours the TT_DEBUG_FLAGS / TT_SB / TT_CHUNK / TT_UNIT / TT_ORDER
+# environment variables (profiling ablations and tuning sweeps, tools/).  The product library above never calls getenv.
+TUNING_LIB_PATH = os.path.join(_HERE, "libtt_hip_tuning.so")
 SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared", "-fno-gpu-rdc"]
 
@@ -31,31 +34,52 @@ def _sources() -> List[str]:
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def needs_build(path: str = LIB_PATH) -> bool:
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(path)
     deps = _sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     deps.append(os.path.join(INCLUDE, "tt_abi.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 ... -shared -> triplaneturbo_amd/libtt_hip.so (in-tree)."""
-    if not force and not needs_build():
-        return LIB_PATH
+def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 ... -shared -> triplaneturbo_amd/libtt_hip.so (in-tree).  One hipcc process per
+    translation unit, in parallel, then a link.  tuning=True builds the dev variant libtt_hip_tuning.so instead."""
+    out = TUNING_LIB_PATH if tuning else LIB_PATH
+    if not force and not needs_build(out):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC]
+    objdir = os.path.join(_HERE, "build", "tuning" if tuning else "release")
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DTT_TUNING"] if tuning else [])
+    procs = []
     for s in _sources():
-        cmd += ["-x", "hip", s]
-    cmd += ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
+        obj = os.path.join(objdir, os.path.basename(s) + ".o")
+        cmd = [hipcc] + flags + ["-I", INCLUDE, "-I", CSRC, "-x", "hip", "-c", s, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    objs = []
+    for obj, pr in procs:
+        so, se = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed ({pr.returncode}):\n{so}\n{se}")
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", out + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+        raise RuntimeError(f"hipcc link failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def use_tuning_build() -> None:
+    """Dev tools only: build and bind the -DTT_TUNING variant for the rest of this process (before the first op)."""
+    global _lib, LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_tuning_build() must be called before the library is first loaded")
+    LIB_PATH = build(tuning=True)
 
 
 _lib: Optional[ctypes.CDLL] = None
@@ -75,7 +99,7 @@ class RenderCfg(ctypes.Structure):
         ("n_prompts", _I32), ("views_per_prompt", _I32), ("plane_h", _I32), ("plane_w", _I32),
         ("rays_per_view", _I32), ("n_samples", _I32), ("n_rays", _I64), ("radius", _F),
         ("sdf_bias_radius", _F), ("inv_std", _F), ("cos_anneal_ratio", _F), ("rgb_grad_shrink", _F),
-        ("flags", _I32), ("image_w", _I32), ("tile_sb", _I32), ("grad_copies", _I32),
+        ("flags", _I32), ("image_w", _I32), ("tile_sb", _I32), ("grad_copies", _I32), ("tile_chunk", _I32),
     ]
 
 
@@ -85,8 +109,10 @@ class HashGridCfg(ctypes.Structure):  # tt_hashgrid_cfg
 
 
 TT_R_PER_SAMPLE = 1
+TT_R_EXACT_F32 = 2
 TT_Q_NORMAL = 1
 TT_Q_TEX = 2
+TT_Q_EXACT_F32 = 4
 
 
 def load() -> ctypes.CDLL:
@@ -110,15 +136,15 @@ def load() -> ctypes.CDLL:
                                     _I32, _P, _P, _P, _P]
     lib.tt_render_fwd.argtypes = [_P, ctypes.POINTER(MlpWeights), _P, _P, _P, _P, ctypes.POINTER(RenderCfg)] + [_P] * 11
     _cfgp, _wp = ctypes.POINTER(RenderCfg), ctypes.POINTER(MlpWeights)
-    lib.tt_query_field.argtypes = [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P]
+    lib.tt_query_field.argtypes = [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P]
     lib.tt_decode_rays.argtypes = [_P, _wp, _P, _P, _P, _P, _cfgp, _I32, _P, _P, _P, _P]
     optional = {
         "tt_render_bwd_geo": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 14 + [_P, _P, _wp, _P],
         "tt_render_bwd_tex": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 4 + [_P, _wp, _P],
         "tt_march_fwd": [_P, _P, _P, _cfgp] + [_P] * 11,
         "tt_march_bwd": [_P, _P, _P, _cfgp] + [_P] * 16,
-        "tt_points_bwd_geo": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F, _P, _P, _P, _P, _wp, _P],
-        "tt_points_bwd_tex": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _wp, _P],
+        "tt_points_bwd_geo": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P, _P, _wp, _P],
+        "tt_points_bwd_tex": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _I32, _I32, _P, _P, _wp, _P],
         "tt_hashgrid_n_params": [ctypes.POINTER(HashGridCfg)],
         "tt_hashgrid_fwd": [_P, _I64, _P, ctypes.POINTER(HashGridCfg), _P, _P],
         "tt_hashgrid_bwd": [_P, _I64, _P, ctypes.POINTER(HashGridCfg), _P, _P],

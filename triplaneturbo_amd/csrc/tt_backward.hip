@@ -106,15 +106,15 @@ template <int VOFF, int VTOT>
 __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const float* Qs, const float (&vec)[VTOT],
                                               const float (&coef)[4], const int (&abs_off)[4], const int (&hs)[4],
                                               float* M, int* tags, float* Ls, int i, int hi, int flags) {
-    const bool no_global = (flags & TT_DBG_NO_GLOBAL_ATOMIC) != 0;
+    const bool no_global = TT_DBG(flags, TT_DBG_NO_GLOBAL_ATOMIC);
     // ---- claim slots and fill M: lane (i, hi) owns corners 2hi, 2hi+1 of sample i ----
     int lost = 0, wrote = 0, mine = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if ((q >> 1) == hi && coef[q] != 0.f) {
             int old = -2;
-            if (flags & TT_DBG_NO_CLAIM) old = -1;
-            else if (!(flags & TT_DBG_NO_COMBINE)) old = atomicCAS(&tags[hs[q]], -1, abs_off[q]);
+            if (TT_DBG(flags, TT_DBG_NO_CLAIM)) old = -1;
+            else if (!TT_DBG(flags, TT_DBG_NO_COMBINE)) old = atomicCAS(&tags[hs[q]], -1, abs_off[q]);
             if (old == -1 || old == abs_off[q]) {
                 M[hs[q] * MS + i] = coef[q];
                 wrote |= 1 << q;
@@ -133,7 +133,7 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
         for (int t4 = 0; t4 < 4; ++t4)
             a4[m][t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
     f32x16 acc0 = ZERO16, acc1 = ZERO16;
-    if (!(flags & TT_DBG_NO_SCATTER_MFMA))
+    if (!TT_DBG(flags, TT_DBG_NO_SCATTER_MFMA))
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const float b = Qs[(t + 16 * hi) * 33 + i];
@@ -233,15 +233,16 @@ struct BwdGeoParams {
 #define GOFF_W2T (GOFF_W1T + IMG16_FLOATS(32, 64))
 #define LDS_GEO16_FLOATS (GOFF_W2T + IMG16_FLOATS(64, 64))
 
+template <bool EXACT>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     __shared__ __attribute__((aligned(16))) float L[LDS_GEO16_FLOATS + 4 * (GEO_SCRATCH_FLOATS + 64)];
     {
         MlpPtrs w = p.w;
-        stage_image16<64, 32, false>(L + OFF_W1, w.w1, 32);
-        stage_image16<64, 64, false>(L + OFF_W2, w.w2, 64);
+        stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
+        stage_weights<EXACT, 64, 64>(L + OFF_W2, w.w2);
         lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
-        stage_image16<32, 64, true>(L + GOFF_W1T, w.w1, 32);
-        stage_image16<64, 64, true>(L + GOFF_W2T, w.w2, 64);
+        stage_weights_t<EXACT, 64, 32>(L + GOFF_W1T, w.w1);
+        stage_weights_t<EXACT, 64, 64>(L + GOFF_W2T, w.w2);
     }
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
@@ -306,10 +307,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                                                   cs, coefs, cfg.flags));
             if (!any) continue;  // exact: no in-bounds texel => f = J = 0, every mask false
             float h1[32], h2[32], a2[32], a1[32], q[16];
-            mv16<64, 32>(L + OFF_W1, f, h1, i, hi);
+            mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mv16<64, 64>(L + OFF_W2, h1, h2, i, hi);
+            mvx<EXACT, 64, 64>(L + OFF_W2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
 #pragma unroll
@@ -318,16 +319,16 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
             }
-            mv16<64, 64>(L + GOFF_W2T, a2, a1, i, hi);
+            mvtx<EXACT, 64, 64>(L + GOFF_W2T, L + OFF_W2, a2, a1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-            mv16<32, 64>(L + GOFF_W1T, a1, q, i, hi);
+            mvtx<EXACT, 32, 64>(L + GOFF_W1T, L + OFF_W1, a1, q, i, hi);
             // ---- network + plane gradients ----
             {
                 float qb[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) qb[r] = fmaf(-sbar, f[r], u[r]);  // qbar = J gbar = u - sbar f
-                const bool do_wgrad = !(cfg.flags & TT_DBG_NO_WGRAD);
+                const bool do_wgrad = !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
                 // dW1 += a1 (sbar f + qbar)^T
                 if (do_wgrad) {
                     stage_rows<64>(Xs, a1, i, hi);
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 }
                 // a1bar = W1 qbar ; b1bar = m1 . a1bar ; v = sbar h1 + b1bar
                 float t1[32];
-                mv16<64, 32>(L + OFF_W1, qb, t1, i, hi);
+                mvx<EXACT, 64, 32>(L + OFF_W1, qb, t1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) t1[r] = h1[r] > 0.f ? t1[r] : 0.f;  // b1bar
                 float v[32];
@@ -350,13 +351,13 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 }
                 // a2bar = W2 b1bar ; dw3 += sbar h2 + m2 . a2bar
                 float t2[32];
-                mv16<64, 64>(L + OFF_W2, t1, t2, i, hi);
+                mvx<EXACT, 64, 64>(L + OFF_W2, t1, t2, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) t2[r] = fmaf(sbar, h2[r], h2[r] > 0.f ? t2[r] : 0.f);
                 stage_rows<64>(Xs, t2, i, hi);
                 accw3 += rowsum32(Xs, lane);
                 // ---- scatter d/d geometry planes: texel(p,c)[ch] += q[ch] * coef(p,c) ----
-                if (!(cfg.flags & TT_DBG_NO_SCATTER)) {
+                if (!TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
                     scatter_clear(Xs, lane);  // M = 0 (Xs held wgrad staging)
                     float* Qs = Ys;           // q staged as [sample][32], stride 33 (same for the 3 planes)
 #pragma unroll
@@ -415,14 +416,15 @@ struct BwdTexParams {
 #define TV1T TEX_W_FLOATS
 #define TEX_W16_FLOATS (TV1T + IMG16_FLOATS(96, 64))
 
+template <bool EXACT>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     __shared__ __attribute__((aligned(16))) float Lt[TEX_W16_FLOATS + 4 * (TEX_SCRATCH_FLOATS + 64)];
     {
         MlpPtrs w = p.w;
-        stage_image16<64, 96, false>(Lt + TV1, w.v1, 96);  // same bytes as the fp32 image it replaces
+        stage_weights<EXACT, 64, 96>(Lt + TV1, w.v1);
         lds_load_matrix(Lt + TV2, w.v2, 64, 64, V2S);
         lds_load_matrix(Lt + TV3, w.v3, 3, 64, 64);
-        stage_image16<96, 64, true>(Lt + TV1T, w.v1, 96);
+        stage_weights_t<EXACT, 64, 96>(Lt + TV1T, w.v1);
     }
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
@@ -495,10 +497,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         if (!any) continue;  // exact: e == 0 => k1 = k2 = 0 and every mask is false
         // e is needed again only as the Y operand of the dV1 outer product: park it in LDS now ([idx][sample]
         // layout, 96 rows) so its 48 registers are free during the MLP chain.
-        const bool do_wgrad = !(cfg.flags & TT_DBG_NO_WGRAD);
+        const bool do_wgrad = !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
         if (do_wgrad) stage_rows<96>(Ys, e, i, hi);
         float k1[32], k2[32];
-        mv16<64, 96>(Lt + TV1, e, k1, i, hi);
+        mvx<EXACT, 64, 96>(Lt + TV1, e, k1, i, hi);
 #pragma unroll
         for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
         mv_fwd<64, 64>(Lt + TV2, k1, k2, i, hi);
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             wgrad<64, 64>(accV2, Xs, Ys, i, hi);
         }
         // ---- ebar = V1^T k1bar (one plane at a time) ; scatter texel(3+p, c)[ch] += w_c * ebar[32p + ch] ----
-        if (!(cfg.flags & TT_DBG_NO_SCATTER)) {
+        if (!TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
             scatter_clear(Xs, lane);  // M = 0 (Xs held wgrad staging)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
                 for (int q4 = 0; q4 < 4; ++q4)  // absolute texel index, prompt included
                     aoff[q4] = (int)(pofs / TT_C) + (int)((3 + pl) * HW) + c.off[q4];
                 float eb[16];  // ebar of this plane = (V1[:, 32pl : 32pl+32])^T k1bar
-                mv16<32, 64>(Lt + TV1T + (size_t)32 * pl * (64 + 4), kb1, eb, i, hi);
+                mvtx<EXACT, 32, 64, V1S>(Lt + TV1T + (size_t)32 * pl * (64 + 4), Lt + TV1 + 32 * pl, kb1, eb, i, hi);
                 float* Es = Ys;  // ebar staged as [sample][32], stride 33
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[r];
@@ -608,8 +610,12 @@ static MlpGradPtrs to_gptrs(const tt_mlp_grads* g) {
 }
 
 static int debug_flags() {
-    const char* e = getenv("TT_DEBUG_FLAGS");  // profiling ablations only
+#ifdef TT_TUNING
+    const char* e = getenv("TT_DEBUG_FLAGS");  // profiling ablations, tuning build only
     return e ? (int)strtol(e, nullptr, 0) : 0;
+#else
+    return 0;
+#endif
 }
 
 // one 4-wave workgroup per CU (register- and LDS-limited), grid a multiple of 8 (XCD chunking)
@@ -618,6 +624,19 @@ static long long persistent_blocks(long long n_items, int cus) {
     long long need = (n_items + 3) / 4;
     if (blocks > need) blocks = need;
     return (blocks + 7) / 8 * 8;
+}
+
+static void launch_bwd_geo(const BwdGeoParams& p, long long blocks, hipStream_t s) {
+    if (p.cfg.flags & TT_R_EXACT_F32)
+        hipLaunchKernelGGL(k_decode_bwd_geo<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(k_decode_bwd_geo<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+static void launch_bwd_tex(const BwdTexParams& p, long long blocks, hipStream_t s) {
+    if (p.cfg.flags & TT_R_EXACT_F32)
+        hipLaunchKernelGGL(k_decode_bwd_tex<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(k_decode_bwd_tex<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 int tt_launch_march_bwd(const float* rays_d, const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,
@@ -666,7 +685,7 @@ extern "C" int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, c
     if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
     p.queue = tt_queue_counters(s);
     if (!p.queue) return TT_ERR_DEVICE;
-    hipLaunchKernelGGL(k_decode_bwd_geo, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    launch_bwd_geo(p, blocks, s);
     return tt_check_launch();
 }
 
@@ -704,7 +723,7 @@ extern "C" int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, c
     if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
     p.queue = tt_queue_counters((hipStream_t)stream);
     if (!p.queue) return TT_ERR_DEVICE;
-    hipLaunchKernelGGL(k_decode_bwd_tex, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    launch_bwd_tex(p, blocks, (hipStream_t)stream);
     return tt_check_launch();
 }
 
@@ -721,7 +740,7 @@ __global__ void k_interleave_ws(const float* __restrict__ g_sdf, const float* __
 
 static int points_cfg(tt_render_cfg* c, int32_t n_batch, int64_t n_points, int32_t n_prompts,
                       int32_t views_per_prompt, int32_t plane_h, int32_t plane_w, float radius, float sdf_bias_radius,
-                      int32_t grad_copies) {
+                      int32_t grad_copies, int32_t q_flags) {
     if (n_batch <= 0 || n_points <= 0 || n_prompts <= 0 || views_per_prompt <= 0) return TT_ERR_BAD_ARG;
     if ((int64_t)n_prompts * views_per_prompt != n_batch || n_points > 0x7fffffffLL) return TT_ERR_BAD_ARG;
     c->n_prompts = n_prompts;
@@ -736,21 +755,22 @@ static int points_cfg(tt_render_cfg* c, int32_t n_batch, int64_t n_points, int32
     c->inv_std = 1.f;  // unused by the decode kernels
     c->cos_anneal_ratio = 1.f;
     c->rgb_grad_shrink = 1.f;
-    c->flags = 0;
+    c->flags = (q_flags & TT_Q_EXACT_F32) ? TT_R_EXACT_F32 : 0;
     c->image_w = 0;
     c->tile_sb = 1;
+    c->tile_chunk = 0;
     c->grad_copies = grad_copies;
     return tt_validate_cfg(c);
 }
 
 extern "C" int tt_points_bwd_geo(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
                                  int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h,
-                                 int32_t plane_w, float radius, float sdf_bias_radius, const float* g_sdf,
-                                 const float* g_sdf_grad, float* workspace, float* grad_packed,
+                                 int32_t plane_w, float radius, float sdf_bias_radius, int32_t flags,
+                                 const float* g_sdf, const float* g_sdf_grad, float* workspace, float* grad_packed,
                                  const tt_mlp_grads* grads, void* stream) {
     tt_render_cfg cfg;
     int st = points_cfg(&cfg, n_batch, n_points, n_prompts, views_per_prompt, plane_h, plane_w, radius,
-                        sdf_bias_radius, 1);
+                        sdf_bias_radius, 1, flags);
     if (st != TT_OK) return st;
     if (!packed || !w || !points || !workspace || !grad_packed || !grads || (!g_sdf && !g_sdf_grad))
         return TT_ERR_BAD_ARG;
@@ -780,16 +800,18 @@ extern "C" int tt_points_bwd_geo(const float* packed, const tt_mlp_weights* w, c
     long long blocks = persistent_blocks(p.n_items, cus);
     p.queue = tt_queue_counters(s);
     if (!p.queue) return TT_ERR_DEVICE;
-    hipLaunchKernelGGL(k_decode_bwd_geo, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    launch_bwd_geo(p, blocks, s);
     return tt_check_launch();
 }
 
 extern "C" int tt_points_bwd_tex(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
                                  int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h,
-                                 int32_t plane_w, float radius, int32_t plane_base, const float* g_features,
-                                 float* grad_packed, const tt_mlp_grads* grads, void* stream) {
+                                 int32_t plane_w, float radius, int32_t plane_base, int32_t flags,
+                                 const float* g_features, float* grad_packed, const tt_mlp_grads* grads,
+                                 void* stream) {
     tt_render_cfg cfg;
-    int st = points_cfg(&cfg, n_batch, n_points, n_prompts, views_per_prompt, plane_h, plane_w, radius, 0.5f, 1);
+    int st = points_cfg(&cfg, n_batch, n_points, n_prompts, views_per_prompt, plane_h, plane_w, radius, 0.5f, 1,
+                        flags);
     if (st != TT_OK) return st;
     if (!packed || !w || !points || !g_features || !grad_packed || !grads) return TT_ERR_BAD_ARG;
     if (!w->v1 || !w->v2 || !w->v3 || !grads->v1 || !grads->v2 || !grads->v3) return TT_ERR_BAD_ARG;
@@ -818,6 +840,6 @@ extern "C" int tt_points_bwd_tex(const float* packed, const tt_mlp_weights* w, c
     long long blocks = persistent_blocks(p.n_items, cus);
     p.queue = tt_queue_counters((hipStream_t)stream);
     if (!p.queue) return TT_ERR_DEVICE;
-    hipLaunchKernelGGL(k_decode_bwd_tex, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    launch_bwd_tex(p, blocks, (hipStream_t)stream);
     return tt_check_launch();
 }

@@ -21,7 +21,15 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// profiling-only ablations, set through the TT_DEBUG_FLAGS env var (results are then WRONG by construction)
+// profiling-only ablations (results are then WRONG by construction).  They exist only in a -DTT_TUNING build of the
+// library (tools/: `_lib.build(tuning=True)`), which also reads the TT_DEBUG_FLAGS / TT_SB / TT_CHUNK / TT_UNIT /
+// TT_ORDER environment variables; the product build compiles every one of these tests to `false` and never calls
+// getenv.
+#ifdef TT_TUNING
+#define TT_DBG(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define TT_DBG(flags, bit) false
+#endif
 #define TT_DBG_NO_SCATTER 0x100
 #define TT_DBG_NO_WGRAD 0x200
 #define TT_DBG_NO_GATHER 0x400
@@ -270,7 +278,7 @@ __device__ __forceinline__ bool gather_geo(const float* __restrict__ planes, int
         for (int k = 0; k < 4; ++k) {
             const f32x4* t = reinterpret_cast<const f32x4*>(planes + (p * HW + (size_t)c.off[k]) * TT_C) + hi;
             f32x4 v[4];
-            if (dbg & TT_DBG_NO_GATHER) {
+            if (TT_DBG(dbg, TT_DBG_NO_GATHER)) {
                 const f32x4 z = {c.w[k], c.du[k], c.dv[k], X};
                 v[0] = v[1] = v[2] = v[3] = z;
             } else {
@@ -332,7 +340,7 @@ __device__ __forceinline__ bool gather_geo_bwd(const float* __restrict__ planes,
         for (int k = 0; k < 4; ++k) {
             const f32x4* t = reinterpret_cast<const f32x4*>(planes + (p * HW + (size_t)c.off[k]) * TT_C) + hi;
             f32x4 v[4];
-            if (dbg & TT_DBG_NO_GATHER) {
+            if (TT_DBG(dbg, TT_DBG_NO_GATHER)) {
                 const f32x4 z = {c.w[k], c.du[k], c.dv[k], X};
                 v[0] = v[1] = v[2] = v[3] = z;
             } else {
@@ -371,7 +379,7 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
         for (int k = 0; k < 4; ++k) {
             const f32x4* t = reinterpret_cast<const f32x4*>(planes + ((3 + p) * HW + (size_t)c.off[k]) * TT_C) + hi;
             f32x4 v[4];
-            if (dbg & TT_DBG_NO_GATHER) {
+            if (TT_DBG(dbg, TT_DBG_NO_GATHER)) {
                 const f32x4 z = {c.w[k], Y, Z, X};
                 v[0] = v[1] = v[2] = v[3] = z;
             } else {
@@ -405,8 +413,8 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
 // (through the object) image regions, and still works on compact groups of pixel blocks (its texels stay in its
 // 4 MB L2).  An XCD's items form a queue ordered chunk-major (local item li -> chunk li / nb, local block li % nb:
 // the waves running concurrently on an XCD work on neighbouring pixel blocks at the SAME depth range) or
-// block-major.  Waves POP items from their XCD's queue (one int32 atomic per item on a counter zeroed by the host
-// before the launch) and, once it is empty, steal from the other XCDs' queues: with static assignment the waves
+// block-major.  Waves POP items from their XCD's queue (one int32 atomic per item on a counter zeroed on the stream
+// in front of the launch, tt_queue_counters) and, once it is empty, steal from the other XCDs' queues: with static assignment the waves
 // were alive only ~75 % of the kernel (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES) because item cost varies ~3x and
 // items-per-wave does not divide evenly.
 struct ItemQueue {
@@ -450,16 +458,6 @@ __device__ __forceinline__ bool item_pop(ItemQueue& q, int order, int n_chunks, 
             return true;
         }
         ++q.hop;
-    }
-    // Every queue is empty for this wave: it will not pop again.  The LAST wave of the launch to get here zeroes the
-    // counters for the next launch that is handed this slot (no per-launch memset on the host: nothing to record
-    // when the launch is captured in a hipGraph, and replays find clean counters).
-    if ((threadIdx.x & 63) == 0) {
-        const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
-        if (atomicAdd(q.ctr + 8, 1) == n_waves - 1) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) atomicExch(q.ctr + k, 0);
-        }
     }
     return false;
 }

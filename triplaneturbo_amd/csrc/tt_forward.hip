@@ -82,7 +82,7 @@ struct DecodeCfg {
 #define OFF_W2T (OFF_W1T + IMG16_FLOATS(32, 64))
 #define LDS_W16_FLOATS (OFF_W2T + IMG16_FLOATS(64, 64))
 
-template <bool NEED_N, bool NEED_TEX>
+template <bool NEED_N, bool NEED_TEX, bool EXACT>
 __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, float px, float py, float pz,
                                            bool valid, int i, int hi, float& s0, float (&gq)[3], float (&c)[3]) {
     const float X = scale_coord(px, dc.radius), Y = scale_coord(py, dc.radius), Z = scale_coord(pz, dc.radius);
@@ -92,17 +92,17 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
     if (NEED_TEX) {
         float e[48];
         bool any = gather_tex(dc.pbase, dc.H, dc.W, X, Y, Z, valid, hi, e, dc.dbg);
-        if (dc.dbg & TT_DBG_NO_MLP) {
+        if (TT_DBG(dc.dbg, TT_DBG_NO_MLP)) {
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 48; ++r) t += e[r];
             c[0] = c[1] = c[2] = t;
         } else if (__any(any)) {  // exact skip: e == 0 for the whole tile => features == 0 (bias-free MLP)
             float k1[32], k2[32];
-            mv16<64, 96>(L + OFF_V1, e, k1, i, hi);
+            mvx<EXACT, 64, 96>(L + OFF_V1, e, k1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
-            mv16<64, 64>(L + OFF_V2, k1, k2, i, hi);
+            mvx<EXACT, 64, 64>(L + OFF_V2, k1, k2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) k2[r] = fmaxf(k2[r], 0.f);
 #pragma unroll
@@ -112,7 +112,7 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
     {
         float f[16], jx[16], jy[16], jz[16];
         bool any = gather_geo<NEED_N>(dc.pbase, dc.H, dc.W, X, Y, Z, valid, dc.ju, dc.jv, hi, f, jx, jy, jz, dc.dbg);
-        if (dc.dbg & TT_DBG_NO_MLP) {
+        if (TT_DBG(dc.dbg, TT_DBG_NO_MLP)) {
             float t = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -127,10 +127,10 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
             gq[2] = tz;
         } else if (__any(any)) {
             float h1[32], h2[32];
-            mv16<64, 32>(L + OFF_W1, f, h1, i, hi);
+            mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mv16<64, 64>(L + OFF_W2, h1, h2, i, hi);
+            mvx<EXACT, 64, 64>(L + OFF_W2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
             s0 = dot_lds<64>(L + OFF_W3, h2, hi);
@@ -143,10 +143,10 @@ __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, 
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
                 }
-                mv16<64, 64>(L + OFF_W2T, a2, a1, i, hi);
+                mvtx<EXACT, 64, 64>(L + OFF_W2T, L + OFF_W2, a2, a1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-                mv16<32, 64>(L + OFF_W1T, a1, q, i, hi);
+                mvtx<EXACT, 32, 64>(L + OFF_W1T, L + OFF_W1, a1, q, i, hi);
                 float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -180,18 +180,18 @@ struct QueryParams {
 };
 
 // weight images of the forward decode kernels: split-fp16 (tt_mfma16.h), W1^T / W2^T only when normals are asked for
-template <bool NEED_N, bool NEED_TEX>
+template <bool NEED_N, bool NEED_TEX, bool EXACT>
 __device__ __forceinline__ void stage_decode_images(float* L, const MlpPtrs& w) {
-    stage_image16<64, 32, false>(L + OFF_W1, w.w1, 32);
-    stage_image16<64, 64, false>(L + OFF_W2, w.w2, 64);
+    stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
+    stage_weights<EXACT, 64, 64>(L + OFF_W2, w.w2);
     lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
     if (NEED_N) {
-        stage_image16<32, 64, true>(L + OFF_W1T, w.w1, 32);
-        stage_image16<64, 64, true>(L + OFF_W2T, w.w2, 64);
+        stage_weights_t<EXACT, 64, 32>(L + OFF_W1T, w.w1);
+        stage_weights_t<EXACT, 64, 64>(L + OFF_W2T, w.w2);
     }
     if (NEED_TEX) {
-        stage_image16<64, 96, false>(L + OFF_V1, w.v1, 96);
-        stage_image16<64, 64, false>(L + OFF_V2, w.v2, 64);
+        stage_weights<EXACT, 64, 96>(L + OFF_V1, w.v1);
+        stage_weights<EXACT, 64, 64>(L + OFF_V2, w.v2);
         lds_load_matrix(L + OFF_V3, w.v3, 3, 64, 64);
     }
 }
@@ -199,10 +199,10 @@ __device__ __forceinline__ void stage_decode_images(float* L, const MlpPtrs& w) 
 // 8 waves (2 per SIMD) share one set of split-fp16 weight images (93 KB: one workgroup per CU)
 #define DECODE_THREADS 512
 
-template <bool NEED_N, bool NEED_TEX>
+template <bool NEED_N, bool NEED_TEX, bool EXACT>
 __global__ __launch_bounds__(DECODE_THREADS) void k_query_points(QueryParams p) {
     __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS];
-    stage_decode_images<NEED_N, NEED_TEX>(L, p.w);
+    stage_decode_images<NEED_N, NEED_TEX, EXACT>(L, p.w);
     __syncthreads();
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const long long tiles_per_batch = (p.n_points + TT_TILE - 1) / TT_TILE;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_query_points(QueryParams p) 
         dc.dbg = 0;
         const float px = p.points[idx * 3 + 0], py = p.points[idx * 3 + 1], pz = p.points[idx * 3 + 2];
         float s0, gq[3], c[3];
-        decode_fwd<NEED_N, NEED_TEX>(L, dc, px, py, pz, valid, i, hi, s0, gq, c);
+        decode_fwd<NEED_N, NEED_TEX, EXACT>(L, dc, px, py, pz, valid, i, hi, s0, gq, c);
         float nrm;
         const float sdf = s0 + sphere_bias(px, py, pz, p.bias_radius, nrm);
         if (valid && hi == 0) {
@@ -266,15 +266,16 @@ struct QueryFieldParams {
     float* out_def;
 };
 
+template <bool EXACT>
 __global__ __launch_bounds__(256, 2) void k_query_field(QueryFieldParams p) {
     __shared__ __attribute__((aligned(16))) float L[LDS_FIELD_FLOATS];
     {  // split-fp16 images (tt_mfma16.h), same footprint as the fp32 ones
         MlpPtrs w = p.w;
-        stage_image16<64, 32, false>(L + OFF_W1, w.w1, 32);
-        stage_image16<64, 64, false>(L + OFF_W2, w.w2, 64);
+        stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
+        stage_weights<EXACT, 64, 64>(L + OFF_W2, w.w2);
         lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
-        stage_image16<64, 32, false>(L + OFF_D1, w.v1, 32);
-        stage_image16<64, 64, false>(L + OFF_D2, w.v2, 64);
+        stage_weights<EXACT, 64, 32>(L + OFF_D1, w.v1);
+        stage_weights<EXACT, 64, 64>(L + OFF_D2, w.v2);
         lds_load_matrix(L + OFF_D3, w.v3, 3, 64, 64);
     }
     __syncthreads();
@@ -298,17 +299,17 @@ __global__ __launch_bounds__(256, 2) void k_query_field(QueryFieldParams p) {
         float s0 = 0.f, d[3] = {0.f, 0.f, 0.f};
         if (any) {  // exact skip otherwise: bias-free MLPs of a zero vector
             float h1[32], h2[32];
-            mv16<64, 32>(L + OFF_W1, f, h1, i, hi);
+            mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mv16<64, 64>(L + OFF_W2, h1, h2, i, hi);
+            mvx<EXACT, 64, 64>(L + OFF_W2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
             s0 = dot_lds<64>(L + OFF_W3, h2, hi);
-            mv16<64, 32>(L + OFF_D1, f, h1, i, hi);
+            mvx<EXACT, 64, 32>(L + OFF_D1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mv16<64, 64>(L + OFF_D2, h1, h2, i, hi);
+            mvx<EXACT, 64, 64>(L + OFF_D2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
 #pragma unroll
@@ -344,10 +345,10 @@ struct DecodeRaysParams {
     float* features;
 };
 
-template <bool NEED_N, bool NEED_TEX>
+template <bool NEED_N, bool NEED_TEX, bool EXACT>
 __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams p) {
     __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS];
-    stage_decode_images<NEED_N, NEED_TEX>(L, p.w);
+    stage_decode_images<NEED_N, NEED_TEX, EXACT>(L, p.w);
     __syncthreads();
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
@@ -386,10 +387,10 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
             float tm, px, py, pz;
             sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
             float s0, gq[3], c[3];
-            decode_fwd<NEED_N, NEED_TEX>(L, dc, px, py, pz, rvalid, i, hi, s0, gq, c);
+            decode_fwd<NEED_N, NEED_TEX, EXACT>(L, dc, px, py, pz, rvalid, i, hi, s0, gq, c);
             float nrm;
             const float sdf = s0 + sphere_bias(px, py, pz, cfg.sdf_bias_radius, nrm);
-            if (rvalid && hi == 0 && !(cfg.flags & TT_DBG_NO_STORE)) {
+            if (rvalid && hi == 0 && !TT_DBG(cfg.flags, TT_DBG_NO_STORE)) {
                 p.sdf[sidx] = sdf;
                 if (NEED_N) {
                     p.sdf_grad[sidx * 3 + 0] = gq[0] + px / nrm;
@@ -474,14 +475,23 @@ extern "C" int tt_query_points(const float* packed, const tt_mlp_weights* w, con
     if (blocks > cus) blocks = cus;
     dim3 grid((unsigned)blocks), block(DECODE_THREADS);
     hipStream_t s = (hipStream_t)stream;
+    const bool exact = (flags & TT_Q_EXACT_F32) != 0;
+#define LAUNCH_QP(N, T)                                                                        \
+    do {                                                                                       \
+        if (exact)                                                                             \
+            hipLaunchKernelGGL((k_query_points<N, T, true>), grid, block, 0, s, p);            \
+        else                                                                                   \
+            hipLaunchKernelGGL((k_query_points<N, T, false>), grid, block, 0, s, p);           \
+    } while (0)
     if (need_n && need_t)
-        hipLaunchKernelGGL((k_query_points<true, true>), grid, block, 0, s, p);
+        LAUNCH_QP(true, true);
     else if (need_n)
-        hipLaunchKernelGGL((k_query_points<true, false>), grid, block, 0, s, p);
+        LAUNCH_QP(true, false);
     else if (need_t)
-        hipLaunchKernelGGL((k_query_points<false, true>), grid, block, 0, s, p);
+        LAUNCH_QP(false, true);
     else
-        hipLaunchKernelGGL((k_query_points<false, false>), grid, block, 0, s, p);
+        LAUNCH_QP(false, false);
+#undef LAUNCH_QP
     return tt_check_launch();
 }
 
@@ -506,7 +516,9 @@ long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom*
     g->image_h = 0;
     g->bpr = g->bpv = 0;
     int sb = cfg->tile_sb;
-    if (const char* e = getenv("TT_SB")) sb = atoi(e);  // tuning only
+#ifdef TT_TUNING
+    if (const char* e = getenv("TT_SB")) sb = atoi(e);
+#endif
     // 0 = auto: 4x4 pixels x 2 samples (measured at the bench shapes: backward 10.1 ms vs 10.5 at sb = 1, 11.8 at 4)
     if (!(sb == 1 || sb == 2 || sb == 4 || sb == 8 || sb == 16 || sb == 32)) sb = 2;
     while (sb > 1 && sb > cfg->n_samples) sb /= 2;
@@ -535,24 +547,34 @@ long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom*
     if (n_chunks < min_chunks) n_chunks = min_chunks;
     if (n_chunks < 1) n_chunks = 1;
     if (n_chunks > n_steps) n_chunks = n_steps;
-    if (const char* e = getenv("TT_CHUNK")) {  // tuning only
+    if (cfg->tile_chunk > 0) {  // explicit samples per work item
+        n_chunks = (cfg->n_samples + cfg->tile_chunk - 1) / cfg->tile_chunk;
+        if (n_chunks > n_steps) n_chunks = n_steps;
+    }
+#ifdef TT_TUNING
+    if (const char* e = getenv("TT_CHUNK")) {
         int c = atoi(e);
         if (c > 0) n_chunks = (cfg->n_samples + c - 1) / c;
         if (n_chunks > n_steps) n_chunks = n_steps;
     }
+#endif
     const int steps_per_chunk = (n_steps + n_chunks - 1) / n_chunks;
     g->chunk = steps_per_chunk * sb;  // always a multiple of sb
     g->n_chunks = (cfg->n_samples + g->chunk - 1) / g->chunk;
     g->n_blocks = n_blocks;
     g->unit = n_blocks / 256;  // >= 32 deal rounds: ragged-round imbalance <= 3 %
     if (g->unit > 32) g->unit = 32;
-    if (const char* e = getenv("TT_UNIT")) {  // tuning only
+#ifdef TT_TUNING
+    if (const char* e = getenv("TT_UNIT")) {
         long long u = atoll(e);
         if (u > 0) g->unit = u;
     }
+#endif
     if (g->unit < 1) g->unit = 1;
     g->order = default_order;
-    if (const char* e = getenv("TT_ORDER")) g->order = atoi(e) ? 1 : 0;  // tuning only
+#ifdef TT_TUNING
+    if (const char* e = getenv("TT_ORDER")) g->order = atoi(e) ? 1 : 0;
+#endif
     return n_blocks * g->n_chunks;
 }
 
@@ -581,7 +603,9 @@ extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const
     p.t_starts = t_starts;
     p.t_ends = t_ends;
     p.cfg = *cfg;
-    if (const char* e = getenv("TT_DEBUG_FLAGS")) p.cfg.flags |= (int)strtol(e, nullptr, 0);  // profiling only
+#ifdef TT_TUNING
+    if (const char* e = getenv("TT_DEBUG_FLAGS")) p.cfg.flags |= (int)strtol(e, nullptr, 0);
+#endif
     p.sdf = sdf;
     p.sdf_grad = sdf_grad;
     p.features = features;
@@ -595,7 +619,10 @@ extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const
     if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
     p.queue = tt_queue_counters(s);
     if (!p.queue) return TT_ERR_DEVICE;
-    hipLaunchKernelGGL((k_decode_rays<true, true>), dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
+    if (cfg->flags & TT_R_EXACT_F32)
+        hipLaunchKernelGGL((k_decode_rays<true, true, true>), dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
+    else
+        hipLaunchKernelGGL((k_decode_rays<true, true, false>), dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
     st = tt_check_launch();
     if (st != TT_OK) return st;
     return tt_launch_march_fwd(rays_d, t_starts, t_ends, cfg, sdf, sdf_grad, features, opacity, depth, rgb_fg,
@@ -639,14 +666,23 @@ extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, cons
     if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
     p.queue = tt_queue_counters(s);
     if (!p.queue) return TT_ERR_DEVICE;
+    const bool exact = ((flags & TT_Q_EXACT_F32) | (cfg->flags & TT_R_EXACT_F32)) != 0;
+#define LAUNCH_DR(N, T)                                                                  \
+    do {                                                                                 \
+        if (exact)                                                                       \
+            hipLaunchKernelGGL((k_decode_rays<N, T, true>), grid, blk, 0, s, p);         \
+        else                                                                             \
+            hipLaunchKernelGGL((k_decode_rays<N, T, false>), grid, blk, 0, s, p);        \
+    } while (0)
     if (need_n && need_t)
-        hipLaunchKernelGGL((k_decode_rays<true, true>), grid, blk, 0, s, p);
+        LAUNCH_DR(true, true);
     else if (need_n)
-        hipLaunchKernelGGL((k_decode_rays<true, false>), grid, blk, 0, s, p);
+        LAUNCH_DR(true, false);
     else if (need_t)
-        hipLaunchKernelGGL((k_decode_rays<false, true>), grid, blk, 0, s, p);
+        LAUNCH_DR(false, true);
     else
-        hipLaunchKernelGGL((k_decode_rays<false, false>), grid, blk, 0, s, p);
+        LAUNCH_DR(false, false);
+#undef LAUNCH_DR
     return tt_check_launch();
 }
 
@@ -654,7 +690,7 @@ extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, cons
 // few_step...:113-122) in v1..v3.
 extern "C" int tt_query_field(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
                               int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h,
-                              int32_t plane_w, float radius, float sdf_bias_radius, float* out_sdf,
+                              int32_t plane_w, float radius, float sdf_bias_radius, int32_t flags, float* out_sdf,
                               float* out_deformation, void* stream) {
     if (!packed || !w || !points || !out_sdf || !out_deformation || n_batch <= 0 || n_points <= 0 || n_prompts <= 0 ||
         views_per_prompt <= 0)
@@ -680,6 +716,9 @@ extern "C" int tt_query_field(const float* packed, const tt_mlp_weights* w, cons
     long long n_tiles = ((n_points + TT_TILE - 1) / TT_TILE) * n_batch;
     long long blocks = (n_tiles + 3) / 4;
     if (blocks > 2LL * cus) blocks = 2LL * cus;
-    hipLaunchKernelGGL(k_query_field, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    if (flags & TT_Q_EXACT_F32)
+        hipLaunchKernelGGL(k_query_field<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(k_query_field<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return tt_check_launch();
 }

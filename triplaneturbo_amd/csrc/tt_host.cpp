@@ -3,7 +3,6 @@
 
 #include <stdlib.h>
 
-#include <atomic>
 #include <mutex>
 
 extern "C" const char* tt_strerror(int status) {
@@ -29,26 +28,61 @@ int tt_num_cus() {
 }
 
 namespace {
-constexpr int kMaxDevices = 64, kSlots = 256, kSlotInts = 16;  // 64 B per slot: one cache line
-int* g_scratch[kMaxDevices] = {};
+// Work-queue counter slots: 64 B each (8 per-XCD heads + padding: one cache line).
+//   * eager launches: ONE slot per (device, stream).  Launches on a stream are ordered, and every launch first
+//     enqueues a 64-byte hipMemsetAsync of its slot on that stream, so a slot is clean whatever happened to the
+//     previous kernel that used it (fault, kill) and two launches that may run concurrently (different streams)
+//     never share counters.
+//   * launches recorded during a stream capture: a slot of their own from a second pool, never handed out again (a
+//     graph may be replayed on any stream, concurrently with eager launches on the capture stream); the memset is
+//     captured as a memset node in front of the kernel node.
+constexpr int kMaxDevices = 64, kStreamSlots = 64, kGraphSlots = 4096, kSlotInts = 16;
+struct DeviceScratch {
+    int* base = nullptr;                 // (kStreamSlots + kGraphSlots) * kSlotInts ints
+    hipStream_t streams[kStreamSlots];   // stream owning eager slot i
+    int n_streams = 0;
+    int n_graph = 0;
+};
+DeviceScratch g_scratch[kMaxDevices];
 std::mutex g_scratch_mu;
-std::atomic<unsigned> g_next_slot{0};
 }  // namespace
 
 int* tt_queue_counters(hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-    int* base;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) return nullptr;
+    int* slot = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_scratch_mu);
-        if (!g_scratch[dev]) {
+        DeviceScratch& d = g_scratch[dev];
+        if (!d.base) {
+            if (cap != hipStreamCaptureStatusNone) return nullptr;  // first use must not be inside a capture
             void* ptr = nullptr;
-            if (hipMalloc(&ptr, (size_t)kSlots * kSlotInts * sizeof(int)) != hipSuccess) return nullptr;
-            if (hipMemset(ptr, 0, (size_t)kSlots * kSlotInts * sizeof(int)) != hipSuccess) return nullptr;
-            g_scratch[dev] = static_cast<int*>(ptr);
+            if (hipMalloc(&ptr, (size_t)(kStreamSlots + kGraphSlots) * kSlotInts * sizeof(int)) != hipSuccess)
+                return nullptr;
+            d.base = static_cast<int*>(ptr);
         }
-        base = g_scratch[dev];
+        if (cap != hipStreamCaptureStatusNone) {
+            if (d.n_graph >= kGraphSlots) return nullptr;
+            slot = d.base + (size_t)(kStreamSlots + d.n_graph++) * kSlotInts;
+        } else {
+            int k = 0;
+            while (k < d.n_streams && d.streams[k] != stream) ++k;
+            if (k == d.n_streams) {
+                if (d.n_streams == kStreamSlots) {
+                    // more distinct streams than slots (stream handles come and go): once the device is idle no
+                    // slot is in use, so the table starts over
+                    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+                    d.n_streams = 0;
+                    k = 0;
+                }
+                ++d.n_streams;
+                d.streams[k] = stream;
+            }
+            slot = d.base + (size_t)k * kSlotInts;
+        }
     }
-    (void)stream;  // the kernels leave their slot zeroed (item_pop): no memset to enqueue
-    return base + (size_t)(g_next_slot.fetch_add(1) % kSlots) * kSlotInts;
+    if (hipMemsetAsync(slot, 0, kSlotInts * sizeof(int), stream) != hipSuccess) return nullptr;
+    return slot;
 }

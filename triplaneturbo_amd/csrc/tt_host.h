@@ -15,8 +15,9 @@ struct TileGeom;
 // its neighbours rather than one depth slab of the whole image share).
 long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g, int default_order);
 
-// Work-queue counters for one kernel launch: 8 zeroed int32 (one per XCD) + a "waves finished" counter in a
-// library-owned device scratch of 256 rotating slots per device, zero-filled once at allocation; every launch leaves
-// its slot zeroed again (the last wave out resets it).  Returns nullptr on a HIP error.  (The only state the library
-// keeps: a 16 KB allocation per device, never freed; first use must not happen inside a stream capture.)
+// Work-queue counters for one kernel launch: 8 int32 heads (one per XCD) in a library-owned device scratch, zeroed on
+// `stream` by a hipMemsetAsync enqueued here (so the caller must launch the kernel on the same stream, next).  One
+// slot per (device, stream) for eager launches, a fresh never-reused slot per launch recorded under stream capture
+// (see tt_host.cpp).  Returns nullptr on a HIP error.  (The only state the library keeps: a 266 KB allocation per
+// device, never freed; its first use must not happen inside a stream capture.)
 int* tt_queue_counters(hipStream_t stream);

@@ -136,3 +136,43 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
             y[16 * m + k] = __builtin_fmaf(acc_l[m][k], un2048, acc_h[m][k] * un);
         }
 }
+
+// ---- precision switch ----------------------------------------------------------------------------------------------
+// EXACT = true (cfg.flags & TT_R_EXACT_F32): every matrix product on v_mfma_f32_32x32x2_f32 (bit-for-bit a k-ordered
+// fmaf chain, 1/16 of the fp16 pipe's rate) from plain fp32 weight images -- the A/B reference for the split-fp16
+// path and an opt-out for users.  The fp32 image of a matrix occupies the same LDS floats as its split-fp16 image
+// (row stride K + 4), so the kernels' LDS maps do not depend on EXACT; the transposed fp16 images are simply unused.
+template <bool EXACT, int ROWS, int K>
+__device__ __forceinline__ void stage_weights(float* dst_f, const float* __restrict__ src) {
+    if constexpr (EXACT) {
+        lds_load_matrix(dst_f, src, ROWS, K, K + 4);
+    } else {
+        stage_image16<ROWS, K, false>(dst_f, src, K);
+    }
+}
+// image of src^T for the `M^T x` products (src is ROWS_SRC x K_SRC row-major); nothing to do when EXACT
+template <bool EXACT, int ROWS_SRC, int K_SRC>
+__device__ __forceinline__ void stage_weights_t(float* dst_f, const float* __restrict__ src) {
+    if constexpr (!EXACT) stage_image16<K_SRC, ROWS_SRC, true>(dst_f, src, K_SRC);
+}
+
+// y[NOUT] = M[NOUT][NIN] x
+template <bool EXACT, int NOUT, int NIN>
+__device__ __forceinline__ void mvx(const float* img, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i, int hi) {
+    if constexpr (EXACT) {
+        mv_fwd<NOUT, NIN>(img, x, y, i, hi);
+    } else {
+        mv16<NOUT, NIN>(img, x, y, i, hi);
+    }
+}
+// y[NOUT] = M^T x for M stored [NIN][STRIDE - 4 columns]: `img_t` is the split-fp16 image of the transposed (slice of)
+// M, `img` the fp32 image of M itself, already offset to the first of the NOUT columns.
+template <bool EXACT, int NOUT, int NIN, int STRIDE = NOUT + 4>
+__device__ __forceinline__ void mvtx(const float* img_t, const float* img, const float (&x)[NIN / 2],
+                                     float (&y)[NOUT / 2], int i, int hi) {
+    if constexpr (EXACT) {
+        mv_bwd<NOUT, NIN, STRIDE>(img, x, y, i, hi);
+    } else {
+        mv16<NOUT, NIN>(img_t, x, y, i, hi);
+    }
+}

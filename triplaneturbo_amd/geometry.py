@@ -95,7 +95,16 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
         return self._gen().forward_denoise(text_embed=text_embed, noisy_input=noisy_input, t=timestep)
 
     def decode(self, latents):
-        return self._gen().forward_decode(latents=latents)  # split_channels v1 is the generator's job here
+        """few_step...:176-196: the generator's decoder emits 2C channels per plane; split_channels "v1" keeps the
+        first C of the three geometry planes and the last C of the three texture planes."""
+        triplane = self._gen().forward_decode(latents=latents)
+        if self.cfg.split_channels is None:
+            return triplane
+        if self.cfg.split_channels != "v1":
+            raise NotImplementedError(f"split_channels={self.cfg.split_channels!r}: only 'v1' / None")
+        assert triplane.shape[1] == 6, "expected (B, 6, 2C, H, W)"
+        c2 = triplane.shape[2] // 2
+        return torch.cat([triplane[:, 0:3, :c2], triplane[:, 3:6, c2:]], dim=1)
 
     # ---- decode half ----
     def mlp_weights(self) -> Tuple[list, list]:
@@ -133,17 +142,21 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
             out.update(normal=normal, shading_normal=normal, sdf_grad=grad)
         return out
 
-    @torch.no_grad()
     def forward_sdf(self, points: Tensor, space_cache: Tensor) -> Tensor:
-        """few_step...:353-373"""
+        """few_step...:353-373.  Differentiable w.r.t. space_cache and the sdf net under autograd (like the
+        reference); the points are constants."""
         B = points.shape[0]
-        pts = points.reshape(B, -1, 3)
-        packed = ops.planes_pack(space_cache.detach())
-        sw, _ = self.mlp_weights()
-        sdf, _, _ = ops.query_points(packed, [w.detach() for w in sw], None, pts.float(),
-                                     views_per_prompt=B // space_cache.shape[0], radius=self.cfg.radius,
-                                     sdf_bias_radius=float(self.cfg.sdf_bias_params), need_normal=False,
-                                     need_features=False)
+        pts = points.reshape(B, -1, 3).detach().float()
+        sw, fw = self.mlp_weights()
+        kw = dict(views_per_prompt=B // space_cache.shape[0], radius=self.cfg.radius,
+                  sdf_bias_radius=float(self.cfg.sdf_bias_params))
+        if self._wants_grad(space_cache, (sw,)):
+            # (the feature head is evaluated too and gets no upstream gradient: its backward is skipped)
+            sdf, _, _ = ops.query_points_grad(space_cache, sw, fw, pts, need_normal=False, **kw)
+        else:
+            with torch.no_grad():
+                sdf, _, _ = ops.query_points(ops.planes_pack(space_cache.detach()), [w.detach() for w in sw], None,
+                                             pts, need_normal=False, need_features=False, **kw)
         return sdf.reshape(*points.shape[:-1], 1)
 
     def forward_field(self, points: Tensor, space_cache: Tensor):

@@ -102,8 +102,10 @@ class RenderConfig:
     inv_std: float = 100.0
     cos_anneal_ratio: float = 1.0
     rgb_grad_shrink: float = 1.0
-    tile_sb: int = 0  # consecutive samples of a ray per kernel tile (performance knob): 0/1 uniform, 4 importance
+    tile_sb: int = 0  # consecutive samples of a ray per kernel tile (performance knob): 0 = default (2), 8 importance
     grad_copies: int = 1  # privatised copies of the plane-gradient buffer in the backward (performance knob)
+    tile_chunk: int = 0  # samples of a ray block per work item (performance knob); 0 = automatic
+    exact_f32: bool = False  # TT_R_EXACT_F32: all matrix products on the fp32-input MFMA (A/B reference, ~1.6x slower)
 
 
 def planes_pack(space_cache: Tensor) -> Tensor:
@@ -151,7 +153,7 @@ def pack_planes(space_cache: Tensor) -> Tensor:
 
 def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Sequence[Tensor]], points: Tensor,
                  views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5,
-                 need_normal: bool = True, need_features: bool = True):
+                 need_normal: bool = True, need_features: bool = True, exact_f32: bool = False):
     """Per-point decode (no grad). points (B,N,3) -> sdf (B*N,1), sdf_grad (B*N,3)|None, features (B*N,3)|None."""
     packed = _chk(packed, "packed")
     points = _chk(points, "points")
@@ -162,7 +164,8 @@ def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Seque
     sdf = torch.empty((B * N, 1), device=dev, dtype=torch.float32)
     grad = torch.empty((B * N, 3), device=dev, dtype=torch.float32) if need_normal else None
     feat = torch.empty((B * N, 3), device=dev, dtype=torch.float32) if need_features else None
-    flags = (_lib.TT_Q_NORMAL if need_normal else 0) | (_lib.TT_Q_TEX if need_features else 0)
+    flags = (_lib.TT_Q_NORMAL if need_normal else 0) | (_lib.TT_Q_TEX if need_features else 0) | (
+        _lib.TT_Q_EXACT_F32 if exact_f32 else 0)
     st = _lib.load().tt_query_points(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, views_per_prompt, H, W,
                                      radius, sdf_bias_radius, flags, _ptr(sdf), _ptr(grad), _ptr(feat), _stream())
     _lib.check(st, "tt_query_points")
@@ -170,7 +173,7 @@ def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Seque
 
 
 def query_field(packed: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tensor], points: Tensor,
-                views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5):
+                views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5, exact_f32: bool = False):
     """sdf (B*N,1) and deformation (B*N,3) from the geometry planes (forward_field)."""
     packed = _chk(packed, "packed")
     points = _chk(points, "points")
@@ -183,7 +186,8 @@ def query_field(packed: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tens
     sdf = torch.empty((B * N, 1), device=points.device, dtype=torch.float32)
     deform = torch.empty((B * N, 3), device=points.device, dtype=torch.float32)
     st = _lib.load().tt_query_field(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, views_per_prompt, H, W,
-                                    radius, sdf_bias_radius, _ptr(sdf), _ptr(deform), _stream())
+                                    radius, sdf_bias_radius, _lib.TT_Q_EXACT_F32 if exact_f32 else 0, _ptr(sdf),
+                                    _ptr(deform), _stream())
     _lib.check(st, "tt_query_field")
     return sdf, deform
 
@@ -225,12 +229,12 @@ class _QueryPointsFn(torch.autograd.Function):
         if g_sdf is not None or g_grad is not None:
             ws = torch.empty((B * N, 4), device=packed.device, dtype=torch.float32)
             st = lib.tt_points_bwd_geo(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius,
-                                       bias_r, _ptr(g_sdf), _ptr(g_grad), _ptr(ws), _ptr(grad_packed),
+                                       bias_r, 0, _ptr(g_sdf), _ptr(g_grad), _ptr(ws), _ptr(grad_packed),
                                        ctypes.byref(gst), _stream())
             _lib.check(st, "tt_points_bwd_geo")
         if g_feat is not None:
             st = lib.tt_points_bwd_tex(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius, 3,
-                                       _ptr(g_feat), _ptr(grad_packed), ctypes.byref(gst), _stream())
+                                       0, _ptr(g_feat), _ptr(grad_packed), ctypes.byref(gst), _stream())
             _lib.check(st, "tt_points_bwd_tex")
         g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
         return (g_cache, *gw, None, None, None, None, None)
@@ -270,21 +274,23 @@ class _QueryFieldFn(torch.autograd.Function):
         B, N, _ = points.shape
         P, _, H, W, _ = packed.shape
         d1x3 = d1.repeat(1, 3).contiguous()  # (64, 96) = [U1 U1 U1]
-        wst = _lib.MlpWeights(*[_ptr(t) for t in (w1.contiguous(), w2.contiguous(), w3.contiguous(), d1x3,
-                                                  d2.contiguous(), d3.contiguous())])
+        keep = [w1.contiguous(), w2.contiguous(), w3.contiguous(), d1x3, d2.contiguous(), d3.contiguous()]
+        wst = _lib.MlpWeights(*[_ptr(t) for t in keep])  # `keep` holds the contiguous copies until the launches
         grad_packed = torch.zeros_like(packed)
         gw = [torch.zeros_like(t) for t in (w1, w2, w3, d1x3, d2, d3)]
         gst = _grads_struct(gw)
         lib = _lib.load()
         if g_sdf is not None:
             ws = torch.empty((B * N, 4), device=packed.device, dtype=torch.float32)
+            g_sdf = g_sdf.contiguous()
             st = lib.tt_points_bwd_geo(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius,
-                                       bias_r, _ptr(g_sdf.contiguous()), None, _ptr(ws), _ptr(grad_packed),
+                                       bias_r, 0, _ptr(g_sdf), None, _ptr(ws), _ptr(grad_packed),
                                        ctypes.byref(gst), _stream())
             _lib.check(st, "tt_points_bwd_geo")
         if g_def is not None:
+            g_def = g_def.contiguous()
             st = lib.tt_points_bwd_tex(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius, 0,
-                                       _ptr(g_def.contiguous()), _ptr(grad_packed), ctypes.byref(gst), _stream())
+                                       0, _ptr(g_def), _ptr(grad_packed), ctypes.byref(gst), _stream())
             _lib.check(st, "tt_points_bwd_tex")
         gw[3] = gw[3].view(64, 3, 32).sum(dim=1)
         g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
@@ -308,9 +314,9 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
     inv_std = min(max(float(rc.inv_std), 1.0e-6), 1.0e6)  # LearnedVariance.forward clamp, renderer :34-35
     return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
                           inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
-                          _lib.TT_R_PER_SAMPLE if per_sample else 0,
+                          (_lib.TT_R_PER_SAMPLE if per_sample else 0) | (_lib.TT_R_EXACT_F32 if rc.exact_f32 else 0),
                           image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0, int(rc.tile_sb),
-                          max(1, int(rc.grad_copies)))
+                          max(1, int(rc.grad_copies)), max(0, int(rc.tile_chunk)))
 
 
 def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
@@ -404,7 +410,7 @@ def march_forward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, sdf: Ten
     cfg = _lib.RenderCfg(n_prompts=1, views_per_prompt=1, plane_h=1, plane_w=1, rays_per_view=n_rays, n_samples=S,
                          n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=rc.inv_std,
                          cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink, flags=0, image_w=0,
-                         tile_sb=0, grad_copies=1)
+                         tile_sb=0, grad_copies=1, tile_chunk=0)
     f32 = dict(device=rays_d.device, dtype=torch.float32)
     if out is None:
         out = {"opacity": torch.empty((n_rays, 1), **f32), "depth": torch.empty((n_rays, 1), **f32),
@@ -431,7 +437,7 @@ def march_backward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, fwd: di
     cfg = _lib.RenderCfg(n_prompts=1, views_per_prompt=1, plane_h=1, plane_w=1, rays_per_view=n_rays, n_samples=S,
                          n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=rc.inv_std,
                          cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink, flags=0, image_w=0,
-                         tile_sb=0, grad_copies=1)
+                         tile_sb=0, grad_copies=1, tile_chunk=0)
     if out is None:
         out = torch.empty((n_rays * S, 4), device=rays_d.device, dtype=torch.float32)
     c = lambda t: None if t is None else t.contiguous()
@@ -471,6 +477,7 @@ class _TriplaneRenderFn(torch.autograd.Function):
                 raw["sdf"], raw["sdf_grad"], raw["features"], raw["trans"])
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g_op, g_depth, g_rgb, g_zvar, g_nacc, g_weights, g_sdf, g_sdf_grad, g_features, _g_trans):
         (packed, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, opacity, depth, trans, weights,
          features, sdf, sdf_grad) = ctx.saved_tensors

@@ -8,6 +8,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Any, Dict, Optional
 
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -117,12 +119,27 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         self.randomized = c.randomized
         self.rgb_grad_shrink = C(c.rgb_grad_shrink, 0, 0)
         self.register_buffer("bbox", torch.as_tensor([[-c.radius] * 3, [c.radius] * 3], dtype=torch.float32))
+        # kernel tile shape under importance sampling (performance only; not a reference knob, so not in Config).
+        # Measured at the reference training shapes (42^2 + 40^2 rays, 193 samples): sb 1/2/4/8/16 =
+        # 14.4/12.9/12.5/12.3/12.8 ms per PatchRenderer forward+backward.
+        self.tile_sb_importance = 8
 
     # ------------------------------------------------------------------------------------------
+    def _inv_std_value(self) -> float:
+        """LearnedVariance.forward's value (exp(10 p) clamped to [1e-6, 1e6], renderer :29-35) as a host float.  The
+        parameter is frozen (trainable_variance=False), so it is read back from the device only when it has been
+        written (load_state_dict / manual assignment bump the tensor version): no host sync per render, and nothing
+        that would be illegal under stream capture."""
+        p = self.variance._inv_std
+        key = (p._version, p.data_ptr())
+        if getattr(self, "_inv_std_cache", (None, None))[0] != key:
+            self._inv_std_cache = (key, min(max(math.exp(float(p.detach()) * 10.0), 1.0e-6), 1.0e6))
+        return self._inv_std_cache[1]
+
     def _render_config(self) -> ops.RenderConfig:
         g = self.geometry.cfg
         return ops.RenderConfig(radius=self.cfg.radius, sdf_bias_radius=float(g.sdf_bias_params),
-                                inv_std=float(self.variance.inv_std), cos_anneal_ratio=float(self.cos_anneal_ratio),
+                                inv_std=self._inv_std_value(), cos_anneal_ratio=float(self.cos_anneal_ratio),
                                 rgb_grad_shrink=float(self.rgb_grad_shrink))
 
     def sample(self, space_cache: Tensor, rays_o: Tensor, rays_d: Tensor, generator=None, packed=None):
@@ -162,7 +179,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         if text_embed is not None:
             assert text_embed.shape[0] == P
         assert B % P == 0, "batch of views must be a multiple of the number of prompts"
-        grad_on = self.training and torch.is_grad_enabled()
+        grad_on = torch.is_grad_enabled()  # the reference stays differentiable in eval mode too
         packed = kwargs.pop("packed", None)  # PatchRenderer packs once for its two renders
         if packed is None:
             with (torch.enable_grad() if grad_on else torch.no_grad()):
@@ -180,7 +197,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         sw, fw = self.geometry.mlp_weights()
         rc = self._render_config()
         if importance_sampled:  # consecutive samples crowd into the same texels: 2x2-pixel x 8-sample tiles
-            rc.tile_sb = 8      # (measured at the reference training shapes: sb 1/2/4/8/16 = 14.4/12.9/12.5/12.3/12.8 ms)
+            rc.tile_sb = self.tile_sb_importance
         ctx = torch.enable_grad() if grad_on else torch.no_grad()
         with ctx:
             out = functional.volume_render(space_cache, sw, fw, rays_o, rays_d, t_starts, t_ends, bg_color,
