@@ -128,6 +128,9 @@ typedef struct {
 
 const char* tt_strerror(int status);
 int tt_abi_version(void);
+/* Test hook: leaves the work-queue counters of `stream` dirty, as a faulted kernel would; the next launch on that
+ * stream must be unaffected (the counters are zeroed on the stream in front of every launch). */
+int tt_debug_poison_queue(void* stream);
 
 /* space_cache (P,6,32,H,W) NCHW  ->  packed (P,6,H,W,32), planes re-oriented per rotate_planes "v1". */
 int tt_planes_pack(const float* space_cache, float* packed, int32_t n_prompts, int32_t plane_h, int32_t plane_w,

@@ -7,17 +7,25 @@ be checked; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 
 Parity status
 -------------
-* plane sampling, MLP decode, first-order normals: PINNED against the
-  importable reference functions (``tests/golden/make_golden.py`` imports
-  ``/root/reference/triplaneturbo_executable`` in the build container and dumps
-  ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` replays them).
-* second-order terms: checked by fp64 ``gradcheck``/``gradgradcheck`` of this
-  restatement (the reference's own double backward is CUDA-only).
-* ray marching (nerfacc v0.5.2 ``render_weight_from_alpha`` /
-  ``accumulate_along_rays`` / ``importance_sampling``): nerfacc is an
-  un-vendored third-party dependency (requirements.txt:5) and the reference
-  has no tests for it => **parity unpinned** at that boundary; the restatement
-  follows nerfacc's published semantics and the reference's call sites.
+* plane sampling, MLP decode, first-order normals: PINNED against the importable reference
+  functions (``tests/golden/make_golden.py`` imports ``/root/reference/triplaneturbo_executable`` in the build
+  container and dumps ``tests/golden/reference_ops.npz``; ``tests/test_oracle_golden.py`` replays them).
+* NeuS alpha, rgb_grad_shrink (+ its C() schedule), NoMaterial, compositing, disparity, camera-space normal maps,
+  training extras, proposal density, render_step_size, and the GRADIENTS of the G6 loss through all of that (rows
+  a14-a16, a19-a21), plus the PatchRenderer composite (a22): PINNED against the reference's OWN renderer classes --
+  ``tests/golden/make_golden_renderer.py`` imports neus_volume_renderer.py, generative_space_sdf_volume_renderer.py,
+  patch_renderer.py, no_material.py and the threestudio utils from /root/reference and RUNS them (fp64 + fp32, forward
+  + autograd backward) on the inputs of render_small.npz -> ``tests/golden/reference_renderer.npz``;
+  ``tests/test_oracle_reference_renderer.py`` checks this file against those vectors (fp64: 1e-15, bit-equal loss),
+  ``tests/test_gpu_backward.py::test_backward_small_golden`` checks the HIP path against them directly.
+* second-order terms: the reference's own double backward is CUDA-only; through the reference renderer run above the
+  second-order path is exercised with THIS file's gather-based bilinear op underneath (itself checked against
+  ``F.grid_sample`` and by fp64 ``gradcheck``/``gradgradcheck``).
+* ray marching (nerfacc v0.5.2 ``render_weight_from_alpha`` / ``accumulate_along_rays`` / ``importance_sampling``,
+  rows a4, a17, a18): nerfacc is an un-vendored third-party CUDA dependency (requirements.txt:5) and the reference has
+  no tests for it => **parity unpinned** at that boundary only; the restatement follows nerfacc's published semantics
+  and the reference's call sites (the golden run above injects an index_add_/segmented-product restatement of the two
+  volrend functions, written independently of the dense one below, and an estimator that returns fixed intervals).
 
 * background hash encoding: tiny-cuda-nn (README.md:74, requirements.txt:6 --
   an un-vendored, UNPINNED git master dependency with no ROCm build) provides

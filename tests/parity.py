@@ -1,0 +1,59 @@
+"""Shared helpers of the GPU parity tests: relative errors against the fp64 and fp32 oracle, and a report file.
+
+Bars (written here so every test states the same thing):
+  * north_star: "gradients matching reference to rtol 1e-4".  The reference is fp32, so the direct comparison is
+    HIP vs the fp32 oracle:  ||g_hip - g_32|| / ||g_32|| <= TOL_VS_FP32 = 1e-4 for d/d planes and the six matrices.
+  * fp64 arbiter: the HIP result must also be as close to the exact (fp64) math as the fp32 oracle is (x3 slack for
+    summation order / atomics), or within 1e-4 of it.
+Every check appends a line to gpurun_out/parity_report.jsonl (copied to profiles/ per round)."""
+import json
+import os
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "parity_report.jsonl")
+TOL_VS_FP32 = 1e-4
+NAMES = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+
+
+def report(case, rows):
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(json.dumps({"case": case, **rows}) + "\n")
+    except OSError:
+        pass
+
+
+def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-4):
+    """g_*: lists of tensors (HIP, fp32 oracle, fp64 oracle) in the order of `names`."""
+    rows = {}
+    for n, a, b32, b64 in zip(names, g_hip, g32, g64):
+        rows[n] = {"hip_vs_fp32": rel(a, b32), "hip_vs_fp64": rel(a, b64), "fp32_vs_fp64": rel(b32, b64)}
+    report(case, rows)
+    for n, r in rows.items():
+        assert r["hip_vs_fp32"] <= tol32, (case, n, rows)
+        assert r["hip_vs_fp64"] <= max(tol64, 3 * r["fp32_vs_fp64"]), (case, n, rows)
+    return rows
+
+
+def check_outputs(case, out_hip, o32, o64, keys, slack=4.0, floor=2e-5):
+    rows = {}
+    for k in keys:
+        want = o64[k].detach().double().cpu()
+        got = out_hip[k].detach().double().cpu().reshape(want.shape)
+        e_hip = (got - want).abs().max().item()
+        w32 = o32[k].detach().double().cpu().reshape(want.shape)
+        e_cpu = (w32 - want).abs().max().item()
+        rows[k] = {"hip_vs_fp64_maxabs": e_hip, "fp32_vs_fp64_maxabs": e_cpu,
+                   "hip_vs_fp32_maxabs": (got - w32).abs().max().item(), "scale": want.abs().max().item()}
+    report(case, rows)
+    for k, r in rows.items():
+        assert r["hip_vs_fp64_maxabs"] <= max(slack * r["fp32_vs_fp64_maxabs"], floor), (case, k, rows)
+    return rows

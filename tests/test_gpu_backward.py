@@ -8,6 +8,8 @@ import torch
 
 from oracle import cpu_ref as O
 
+from parity import check_grads
+
 pytestmark = pytest.mark.gpu
 
 
@@ -60,20 +62,15 @@ NAMES = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "fea
 
 
 def _check(g_hip, g32, g64, tol=1e-4):
-    rep = {}
-    for n, a, b32, b64 in zip(NAMES, g_hip, g32, g64):
-        e_hip, e_cpu = _rel(a, b64), _rel(b32, b64)
-        amax = (a.double() - b64).abs().max().item() / b64.abs().max().item()
-        rep[n] = (e_hip, e_cpu, amax)
-    for n, (e_hip, e_cpu, amax) in rep.items():
-        # gradients match the exact (fp64) reference math to rtol 1e-4 in norm, or at least as well as the
-        # fp32 CPU restatement of the same math does (x3 slack for the different summation order / atomics).
-        assert e_hip <= max(tol, 3 * e_cpu), (n, rep)
-    return rep
+    """Both bars of tests/parity.py: ||hip - fp32 oracle|| / ||fp32 oracle|| <= 1e-4 (north_star's rtol against the
+    fp32 reference math), and as close to the exact fp64 math as the fp32 oracle is."""
+    case = os.environ.get("PYTEST_CURRENT_TEST", "test_gpu_backward").split("::")[-1].split(" ")[0]
+    return check_grads(case, g_hip, g32, g64, tol64=tol)
 
 
 def test_backward_small_golden(mods, golden_dir):
     k = dict(np.load(os.path.join(golden_dir, "render_small.npz")))
+    kref = dict(np.load(os.path.join(golden_dir, "reference_renderer.npz")))  # the REFERENCE renderer's own results
     sw = [T(k[f"sdf_w{i}"]) for i in range(3)]
     fw = [T(k[f"feat_w{i}"]) for i in range(3)]
     proj = {n: T(k[f"proj_{n}"]) for n, _ in KEYS}
@@ -91,6 +88,20 @@ def test_backward_small_golden(mods, golden_dir):
         e32 = (T(k[f"f32_{key}"]).double() - want).abs().max().item()
         assert (got - want).abs().max().item() <= max(4 * e32, 2e-5), key
     print(_check(g, g32, g64))
+    # directly against what the reference's renderer classes computed on these inputs (make_golden_renderer.py)
+    gr32 = [T(kref["f32_g_cache"])] + [T(kref[f"f32_g_sdf_w{i}"]) for i in range(3)] + [
+        T(kref[f"f32_g_feat_w{i}"]) for i in range(3)]
+    gr64 = [T(kref["f64_g_cache"])] + [T(kref[f"f64_g_sdf_w{i}"]) for i in range(3)] + [
+        T(kref[f"f64_g_feat_w{i}"]) for i in range(3)]
+    print(check_grads("golden case vs the reference renderer's own gradients", g, gr32, gr64))
+    for key in ("comp_rgb", "opacity", "depth", "z_variance", "disparity", "comp_normal", "comp_normal_cam_vis",
+                "comp_normal_cam_vis_white", "weights", "sdf", "sdf_orig", "features", "sdf_grad", "normal", "points",
+                "t_points", "t_intervals", "t_dirs"):
+        want = T(kref[f"f64_{key}"])
+        got = out[key].detach().cpu().double().reshape(want.shape)
+        e32 = (T(kref[f"f32_{key}"]).double() - want).abs().max().item()
+        assert (got - want).abs().max().item() <= max(4 * e32, 2e-5), key
+    assert torch.equal(out["ray_indices"].cpu(), T(kref["f64_ray_indices"]))
 
 
 @pytest.mark.parametrize("P,R,n_view,Hh,Ww,S,seed", [

@@ -86,3 +86,13 @@ int* tt_queue_counters(hipStream_t stream) {
     if (hipMemsetAsync(slot, 0, kSlotInts * sizeof(int), stream) != hipSuccess) return nullptr;
     return slot;
 }
+
+// Test hook (tests/test_gpu_graph.py): fills the work-queue slot the next eager launch on `stream` will use with
+// garbage, as a faulted or killed kernel would leave it.  The launch must still pop every item, because
+// tt_queue_counters zeroes the slot on the stream in front of every launch.
+extern "C" int tt_debug_poison_queue(void* stream) {
+    int* slot = tt_queue_counters((hipStream_t)stream);
+    if (!slot) return TT_ERR_DEVICE;
+    return hipMemsetAsync(slot, 0x7f, kSlotInts * sizeof(int), (hipStream_t)stream) == hipSuccess ? TT_OK
+                                                                                                 : TT_ERR_DEVICE;
+}

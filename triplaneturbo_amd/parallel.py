@@ -45,3 +45,50 @@ def allreduce_mlp_grads(params: Sequence[torch.Tensor], dist, average: bool = Tr
     if average:
         flat /= dist.get_world_size()
     unflatten_into_grads(flat, params)
+
+
+class FlatGradBucket:
+    """The renderer-side parameters' gradients as views of ONE pre-flattened buffer (what DDP calls
+    gradient_as_bucket_view): autograd accumulates straight into `p.grad` (= a view of `flat_grad`), so the
+    per-backward exchange is a single in-place all-reduce of `flat_grad` -- no cat, no copy-back, no temporaries.
+
+        bucket = FlatGradBucket(sdf_weights + feat_weights)    # once
+        bucket.zero_()                                          # instead of p.grad = None
+        loss.backward()
+        bucket.all_reduce(dist)                                 # one RCCL call on the current stream
+    """
+
+    def __init__(self, params: Sequence[torch.Tensor]):
+        self.params = list(params)
+        if not self.params:
+            raise ValueError("no parameters")
+        p0 = self.params[0]
+        n = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(n, dtype=p0.dtype, device=p0.device)
+        self.bind()
+
+    def bind(self) -> None:
+        """(re)attach the views -- call again if something replaced p.grad (e.g. `p.grad = None`)"""
+        ofs = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat_grad[ofs:ofs + n].view_as(p)
+            ofs += n
+
+    def zero_(self) -> None:
+        self.flat_grad.zero_()
+        if any(p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr() or
+               p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * self.flat_grad.element_size()
+               for p in self.params):
+            self.bind()
+
+    def all_reduce(self, dist, average: bool = True):
+        """Sum (DDP: average) over ranks, in place.  Returns the async work handle when async_op is supported and
+        wanted by the caller (`wait()` before the optimizer step); here the collective is enqueued on the current
+        stream, behind the backward kernels that produced flat_grad, and the caller's next kernels queue behind it."""
+        if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            return None
+        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+        if average:
+            self.flat_grad /= dist.get_world_size()
+        return None
