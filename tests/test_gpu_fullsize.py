@@ -14,7 +14,7 @@ def full():
         pytest.skip("needs a GPU")
     import bench
     from triplaneturbo_amd import ops
-    inp = bench.make_inputs(0, torch.device("cuda", 0))
+    inp = bench.make_inputs(0, 1, torch.device("cuda", 0), 1)
     return bench, ops, inp
 
 

@@ -6,7 +6,7 @@ from triplaneturbo_amd import _lib
 _lib.use_tuning_build()  # -DTT_TUNING variant (honours TT_DEBUG_FLAGS)
 from triplaneturbo_amd import ops
 dev = torch.device("cuda", 0)
-inp = bench.make_inputs(0, dev)
+inp = bench.make_inputs(0, 1, dev, 1)
 rc = ops.RenderConfig()
 packed = ops.planes_pack(inp["cache"].detach())
 sw = [w.detach() for w in inp["sw"]]; fw = [w.detach() for w in inp["fw"]]

@@ -14,7 +14,7 @@ from triplaneturbo_amd import functional, ops  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda", 0)
-inp = bench.make_inputs(0, dev)
+inp = bench.make_inputs(0, 1, dev, 1)
 rc = ops.RenderConfig()
 params = [inp["cache"]] + inp["sw"] + inp["fw"]
 

@@ -10,7 +10,7 @@ import bench  # noqa: E402
 from triplaneturbo_amd import functional, ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
-inp = bench.make_inputs(0, dev)
+inp = bench.make_inputs(0, 1, dev, 1)
 rc = ops.RenderConfig()
 params = [inp["cache"]] + inp["sw"] + inp["fw"]
 for p in params:

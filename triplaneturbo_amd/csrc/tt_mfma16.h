@@ -1,19 +1,25 @@
 // tt_mfma16.h -- fp32-accurate mat-vec products on the fp16 matrix pipe (v_mfma_f32_32x32x16_f16, 16x the rate of
 // v_mfma_f32_32x32x2_f32 on gfx950).
 //
-// Every fp32 operand is split in two fp16 terms, v = hi + lo' / 2048 with hi = f16(v) and lo' = f16((v - hi) * 2048)
-// (v - hi is exact in fp32; the 2^11 factor keeps lo' out of the fp16 subnormals), so hi + lo'/2048 carries 22
-// significand bits.  A product keeps the three terms above 2^-22:
-//      a b  ~=  a_hi b_hi  +  (a_hi b_lo' + a_lo' b_hi) / 2048
-// = 3 MFMAs per 16-deep k-step (fp16 x fp16 products are exact, accumulation is fp32 inside the MFMA) instead of 8
-// fp32 MFMAs of twice the issue time: 5.3x less matrix-pipe time.  Relative error per product <= 2^-21 (round toward
-// zero conversions), i.e. fp32-grade for these 32..96-term dot products whose fp32 accumulation error is ~sqrt(K) 2^-24.
+// Every fp32 operand is split in two fp16 terms, v = hi + lo with hi = f16(v) and lo = f16(v - hi)  (v - hi is exact
+// in fp32).  Operands are first normalised by a power of two so that the largest |v| of the matrix / of the sample's
+// activation vector sits in [2^14, 2^15) -- the TOP of the fp16 range -- so that lo (< 2^-10 |v|) is a NORMAL fp16
+// number, i.e. hi + lo carries 22 significand bits, for every entry within 2^-19 of the largest (below that lo is an
+// fp16 subnormal, which the gfx950 MFMA honours -- tools/mfma16_probe.hip -- at an absolute 2^-24, i.e. 2^-39 of the
+// largest entry).  A product keeps the three terms above 2^-20:
+//      a b  ~=  a_hi b_hi + a_hi b_lo + a_lo b_hi
+// = 3 MFMAs per 16-deep k-step into ONE fp32 accumulator (fp16 x fp16 products are exact, accumulation is fp32 inside
+// the MFMA) instead of 8 fp32 MFMAs of twice the issue time: 5.3x less matrix-pipe time.  Error per dot product
+// <= ~2^-23 |a|max |b|max per term, i.e. fp32-grade norm-wise (fp32 accumulation itself is ~sqrt(K) 2^-24).
+// (Round 1 normalised to [0.5, 1) and scaled lo by 2^11 to keep it normal, which needed a second accumulator set per
+// row tile -- 32 more registers in a 64-row product -- and a combine pass over the outputs: forward 2.15 -> 1.94 ms,
+// backward 4.13 / 5.84 -> 3.97 / 5.68 ms with the single accumulator.)
 //
 // Layout.  Activations stay in the LIDX register layout of tt_device.h (reg r of lane (j, hi) <-> element
 // (r&3) + 8(r>>2) + 4hi): the 8 registers 8s..8s+7 of a lane are the 8 k-slots that lane feeds to k-step s of a
 // 32x32x16 MFMA (B operand); which element sits in which slot does not matter as long as the A operand uses the same
 // assignment, so the weight image is stored pre-permuted: row R of a [ROWS][K] matrix holds, for k-step s, term t in
-// {hi, lo'} and half-wave h, the 8 halfs  W[R][16s + (j&3) + 8(j>>2) + 4h], j = 0..7  at
+// {hi, lo} and half-wave h, the 8 halfs  W[R][16s + (j&3) + 8(j>>2) + 4h], j = 0..7  at
 //      R * (2K + 8) + ((2s + t) * 2 + h) * 8      (in halfs)
 // i.e. exactly the bytes and the 16-byte-per-lane, conflict-free read pattern of the fp32 image (row stride K+4
 // floats).  `W^T x` products use a second image built from the transposed matrix.
@@ -29,14 +35,14 @@ typedef _Float16 half_t;
 __device__ __forceinline__ void split16(float v, half_t& hi, half_t& lo) {
     const h2_t p = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(v, 0.f));
     hi = p.x;
-    const h2_t q = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz((v - (float)hi) * 2048.f, 0.f));
+    const h2_t q = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(v - (float)hi, 0.f));  // may be subnormal
     lo = q.x;
 }
 
 // Builds the image of M (ROWS x K).  src is row-major: M[R][c] = src[R * ld + c], or, with TRANSPOSED, the image of
 // src^T: M[R][c] = src[c * ld + R].  The matrix is first normalised by the power of two that brings its largest
-// |entry| into [0.5, 1) (exact; any weight scale, from 1e-30 to 1e30, then splits with full precision and nothing can
-// overflow fp16); the inverse factor is stored in the first pad float of EVERY row (so row slices of an image carry
+// |entry| into [2^14, 2^15) (exact; any weight scale, from 1e-30 to 1e30, then splits with full precision and nothing
+// can overflow fp16); the inverse factor is stored in the first pad float of EVERY row (so row slices of an image carry
 // it) and mv16 folds it into its result scaling.  All threads of the workgroup must call this (it synchronises).
 template <int ROWS, int K, bool TRANSPOSED>
 __device__ __forceinline__ void stage_image16(float* dst_f, const float* __restrict__ src, int ld) {
@@ -50,9 +56,9 @@ __device__ __forceinline__ void stage_image16(float* dst_f, const float* __restr
     atomicMax(slot, __builtin_bit_cast(unsigned, m));  // non-negative floats order like their bit patterns
     __syncthreads();
     int E = (int)(*slot >> 23);
-    E = E < 12 ? 12 : (E > 240 ? 240 : E);
-    const float sc = __builtin_bit_cast(float, (unsigned)(253 - E) << 23);  // 2^(126 - e)
-    const float un = __builtin_bit_cast(float, (unsigned)(E + 1) << 23);    // 1 / sc
+    E = E < 16 ? 16 : (E > 240 ? 240 : E);
+    const float sc = __builtin_bit_cast(float, (unsigned)(268 - E) << 23);  // 2^(141 - E): max |entry| -> [2^14, 2^15)
+    const float un = __builtin_bit_cast(float, (unsigned)(E - 14) << 23);   // 1 / sc
     __syncthreads();
     for (int e = threadIdx.x; e < ROWS * K; e += blockDim.x) {
         const int R = e / K, c = e - R * K;
@@ -73,7 +79,7 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 
 // y[NOUT] = M[NOUT][NIN] x[NIN], M given as an image; x, y in the LIDX register layout.
 // SCALED: every sample (= MFMA column = this lane and its partner lane ^ 32) is first normalised by the power of two
-// that brings its largest |x| into [0.5, 1) and the result is scaled back -- exact, and it makes the product
+// that brings its largest |x| into [2^14, 2^15) and the result is scaled back -- exact, and it makes the product
 // independent of the magnitude of x (gradient chains carry values of 1e-10 that fp16 cannot hold; columns of a
 // mat-vec are independent, so each gets its own exponent).
 template <int NOUT, int NIN, bool SCALED = true>
@@ -82,25 +88,21 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
     constexpr int MT = NOUT / 32, KS = NIN / 16, RS = 2 * NIN + 8;
     const half_t* row = reinterpret_cast<const half_t*>(img_f) + (size_t)i * RS + 8 * hi;
     const float wun = img_f[(size_t)i * (NIN + 4) + NIN];  // inverse of the matrix normalisation (stage_image16)
-    float sc = 1.f, sc2048 = 2048.f, un = wun, un2048 = wun * (1.f / 2048.f);
+    float sc = 1.f, un = wun;
     if (SCALED) {
         float m = 0.f;
 #pragma unroll
         for (int r = 0; r < NIN / 2; ++r) m = fmaxf(m, __builtin_fabsf(x[r]));
         m = fmaxf(m, __shfl_xor(m, 32));
         int E = (int)(__builtin_bit_cast(unsigned, m) >> 23);  // biased exponent (m >= 0)
-        E = E < 12 ? 12 : (E > 240 ? 240 : E);                 // keeps all four factors normal
-        sc = __builtin_bit_cast(float, (unsigned)(253 - E) << 23);         // 2^(126 - e): max |x| -> [0.5, 1)
-        sc2048 = __builtin_bit_cast(float, (unsigned)(264 - E) << 23);     // sc * 2^11
-        un = wun * __builtin_bit_cast(float, (unsigned)(E + 1) << 23);        // 1 / sc
-        un2048 = wun * __builtin_bit_cast(float, (unsigned)(E - 10) << 23);   // 1 / (sc * 2^11)
+        E = E < 16 ? 16 : (E > 240 ? 240 : E);                 // keeps both factors normal
+        sc = __builtin_bit_cast(float, (unsigned)(268 - E) << 23);       // 2^(141 - E): max |x| -> [2^14, 2^15)
+        un = wun * __builtin_bit_cast(float, (unsigned)(E - 14) << 23);  // 1 / sc
     }
-    f32x16 acc_h[MT], acc_l[MT];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        acc_h[m] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc_l[m] = acc_h[m];
-    }
+    for (int m = 0; m < MT; ++m)
+        acc[m] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         // split the 8 activations of this k-step
@@ -109,32 +111,34 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
         for (int j = 0; j < 4; ++j) {
             const f2_t ab = {x[8 * s + 2 * j], x[8 * s + 2 * j + 1]};
             const f2_t as = SCALED ? ab * sc : ab;  // exact (power of two)
-            const f2_t a2k = ab * sc2048;
             const h2_t p = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(as.x, as.y));
-            const float ra = __builtin_fmaf((float)p.x, -2048.f, a2k.x);
-            const float rb = __builtin_fmaf((float)p.y, -2048.f, a2k.y);
+            const float ra = as.x - (float)p.x, rb = as.y - (float)p.y;  // exact residuals
             const h2_t q = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(ra, rb));
             bh[2 * j] = p.x;
             bh[2 * j + 1] = p.y;
             bl[2 * j] = q.x;
             bl[2 * j + 1] = q.y;
         }
+        // the three terms of a row tile go to the same accumulator; row tiles are interleaved so that consecutive
+        // MFMAs never depend on each other when MT > 1
+        h8_t ah[MT], al[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const half_t* a = row + (size_t)(32 * m) * RS + 32 * s;
-            const h8_t ah = *reinterpret_cast<const h8_t*>(a);
-            const h8_t al = *reinterpret_cast<const h8_t*>(a + 16);
-            acc_h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_h[m], 0, 0, 0);
-            acc_l[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_l[m], 0, 0, 0);
-            acc_l[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_l[m], 0, 0, 0);
+            ah[m] = *reinterpret_cast<const h8_t*>(a);
+            al[m] = *reinterpret_cast<const h8_t*>(a + 16);
         }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            y[16 * m + k] = __builtin_fmaf(acc_l[m][k], un2048, acc_h[m][k] * un);
-        }
+        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k] * un;
 }
 
 // ---- precision switch ----------------------------------------------------------------------------------------------

@@ -23,12 +23,14 @@ class KernelTimer:
     def __init__(self):
         self.events = []  # (label, start, end)
 
-    def summary(self):
+    def summary(self, median: bool = False):
+        """label -> (mean or median duration in ms, number of launches)"""
         torch.cuda.synchronize()
         acc = {}
         for label, a, b in self.events:
             acc.setdefault(label, []).append(a.elapsed_time(b))
-        return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+        mid = (lambda v: sorted(v)[len(v) // 2]) if median else (lambda v: sum(v) / len(v))
+        return {k: (mid(v), len(v)) for k, v in acc.items()}
 
 
 _TIMER: Optional[KernelTimer] = None
