@@ -40,6 +40,8 @@
  *   tt_render_bwd_geo /     the autograd backward of the same, incl. the second-order terms the reference
  *   tt_render_bwd_tex       obtains from gridsample_cuda.cu:27-210 (grad2_2d, cuda_gridsample.py:68-79),
  *                           aten grid_sampler_2d_backward and the transposed cuBLAS GEMMs.
+ *   tt_points_bwd_x         the same backward w.r.t. the query points themselves (grad_grid of both grid_sample
+ *                           backwards + K1's grad_grid, gridsample_cuda.cu:196-208)
  *   tt_points_bwd_geo /     the autograd backward of tt_query_points / tt_query_field w.r.t. planes and MLP weights
  *   tt_points_bwd_tex       (training-time callers: generative_space_mesh_rasterize_renderer.py:428-452 field
  *                           query, :321-376 per-pixel geometry decode); same kernels as tt_render_bwd_*.
@@ -225,8 +227,8 @@ int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, const float*
                       const float* features, const float* g_rgb_fg, const float* g_features, float* grad_packed,
                       const tt_mlp_grads* grads, void* stream);
 
-/* Backward of the per-point queries.  points (n_batch, n_points, 3) as in tt_query_points (constants: no
- * gradient w.r.t. the points is produced).
+/* Backward of the per-point queries.  points (n_batch, n_points, 3) as in tt_query_points
+ * (constants here: the gradient w.r.t. the points is tt_points_bwd_x)
  * _geo: upstream g_sdf (n) and/or g_sdf_grad (n,3) (one may be null) -> d/d geometry planes 0..2 (accumulated into
  *       grad_packed, caller zero-fills) and d/d sdf net (grads->w1..w3).  workspace: n*4 floats.
  * _tex: upstream g_features (n,3) of a 96->64->64->3 net in w->v1..v3 reading planes plane_base..plane_base+2 of
@@ -241,6 +243,19 @@ int tt_points_bwd_tex(const float* packed, const tt_mlp_weights* w, const float*
                       int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
                       float radius, int32_t plane_base, int32_t flags, const float* g_features, float* grad_packed,
                       const tt_mlp_grads* grads, void* stream);
+
+/* Gradient of the per-point decode w.r.t. the QUERY POINTS (the reference keeps `points` in the autograd graph:
+ * few_step...:283-286,329-335; caller generative_space_mesh_rasterize_renderer.py:307-331): for upstream g_sdf (n),
+ * g_sdf_grad (n,3), g_features (n,3) (any may be null = 0)
+ *   grad_points (n,3) = g_sdf d sdf/dx + d (g_sdf_grad . sdf_grad)/dx + (d features/dx)^T g_features,
+ * i.e. aten grid_sampler_2d_backward's grad_grid for sdf / features and K1's `grad_grid` output
+ * (gridsample_cuda.cu:196-208: the cross derivative of the bilinear interpolation) plus the sphere bias's Hessian for the
+ * second-order term.  Overwrites grad_points.  flags: TT_Q_EXACT_F32 or 0.  (d/d planes and d/d weights of the same
+ * upstream come from tt_points_bwd_geo / _tex.) */
+int tt_points_bwd_x(const float* packed, const tt_mlp_weights* w, const float* points, int32_t n_batch,
+                    int64_t n_points, int32_t n_prompts, int32_t views_per_prompt, int32_t plane_h, int32_t plane_w,
+                    float radius, int32_t flags, const float* g_sdf, const float* g_sdf_grad, const float* g_features,
+                    float* grad_points, void* stream);
 
 /* Multiresolution hash encoding of 3-D points in [0,1]^3 (tcnn "HashGrid", Linear interpolation, fp32).
  * params: flat table, level-major, entry-major, feature-minor (tcnn's `params` layout), tt_hashgrid_n_params floats

@@ -93,3 +93,51 @@ def test_forward_field_is_differentiable():
     g_hip = torch.autograd.grad(loss, params)
     _check(g_hip, g32, g64, ["planes", "w1", "w2", "w3", "d1", "d2", "d3"])
     assert g_hip[0][:, 3:].abs().max().item() == 0.0  # texture planes are not touched by the field query
+
+
+@pytest.mark.parametrize("output_normal", [True, False])
+def test_gradient_wrt_the_query_points(output_normal):
+    """the raster renderer decodes positions interpolated from differentiable mesh vertices, so
+    d loss / d points must flow (first order through sdf / features, second order through sdf_grad / normal: K1's
+    grad_grid output, gridsample_cuda.cu:196-208).  Against autograd of the oracle with points.requires_grad_()."""
+    from parity import report
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(21)
+    g = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
+    gen = torch.Generator().manual_seed(22)
+    P, vpp, N, R = 2, 2, 257, 48
+    cache = torch.randn(P, 6, 32, R, R, generator=gen) * 0.5
+    pts = torch.rand(P * vpp, N, 3, generator=gen) * 2.2 - 1.1  # some outside the box (zeros padding)
+    sw = [w.detach().cpu() for w in g.sdf_network.weights()]
+    fw = [w.detach().cpu() for w in g.feature_network.weights()]
+    keys = ("sdf", "features") + (("sdf_grad", "normal") if output_normal else ())
+    proj = {k: torch.randn(P * vpp * N, 1 if k == "sdf" else 3, generator=gen) for k in keys}
+
+    def oracle(dt):
+        x = pts.to(dt).requires_grad_(True)
+        c = cache.to(dt).requires_grad_(True)
+        o = O.geometry_forward(x, c.repeat_interleave(vpp, 0), [w.to(dt) for w in sw], [w.to(dt) for w in fw],
+                               output_normal=output_normal, create_graph=True)
+        loss = sum((o[k] * proj[k].to(dt)).sum() for k in keys)
+        return torch.autograd.grad(loss, [x, c])
+
+    gx32, gc32 = oracle(torch.float32)
+    gx64, gc64 = oracle(torch.float64)
+    x = pts.to(dev).requires_grad_(True)
+    c = cache.to(dev).requires_grad_(True)
+    out = g(x, c, output_normal=output_normal)
+    loss = sum((out[k] * proj[k].to(dev)).sum() for k in keys)
+    gx, gc = torch.autograd.grad(loss, [x, c])
+    e_hip, e_cpu, e_32 = _rel(gx.cpu(), gx64), _rel(gx32, gx64), _rel(gx.cpu(), gx32)
+    report(f"d/d points of geometry.forward (output_normal={output_normal})",
+           {"hip_vs_fp64": e_hip, "fp32_vs_fp64": e_cpu, "hip_vs_fp32": e_32})
+    assert e_hip <= max(1e-4, 3 * e_cpu), (e_hip, e_cpu)
+    assert e_32 <= 1e-4, e_32
+    _check([gc], [gc32], [gc64], ["planes"])
+    # points only (frozen planes and weights): the plane / weight backward kernels are skipped altogether
+    for w_ in g.parameters():
+        w_.requires_grad_(False)
+    x2 = pts.to(dev).requires_grad_(True)
+    out2 = g(x2, cache.to(dev), output_normal=output_normal)
+    gx2, = torch.autograd.grad(sum((out2[k] * proj[k].to(dev)).sum() for k in keys), [x2])
+    torch.testing.assert_close(gx2, gx, rtol=1e-6, atol=1e-7)

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libtt_hip.so")
 # dev-only variant built with -DTT_TUNING: honours the TT_DEBUG_FLAGS / TT_SB / TT_CHUNK / TT_UNIT / TT_ORDER
 # environment variables (profiling ablations and tuning sweeps, tools/).  The product library above never calls getenv.
 TUNING_LIB_PATH = os.path.join(_HERE, "libtt_hip_tuning.so")
-SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
+SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_points.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared", "-fno-gpu-rdc"]
 
 # every symbol include/tt_abi.h declares (tests check the header and this list agree)
@@ -26,7 +26,7 @@ SYMBOLS = [
     "tt_strerror", "tt_abi_version", "tt_planes_pack", "tt_planes_unpack_grad", "tt_query_points",
     "tt_query_field", "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2",
     "tt_march_fwd", "tt_march_bwd", "tt_sample_uniform", "tt_sample_importance",
-    "tt_points_bwd_geo", "tt_points_bwd_tex", "tt_hashgrid_n_params", "tt_hashgrid_fwd", "tt_hashgrid_bwd",
+    "tt_points_bwd_geo", "tt_points_bwd_tex", "tt_points_bwd_x", "tt_hashgrid_n_params", "tt_hashgrid_fwd", "tt_hashgrid_bwd",
     "tt_debug_poison_queue",
 ]
 
@@ -146,6 +146,7 @@ def load() -> ctypes.CDLL:
         "tt_march_bwd": [_P, _P, _P, _cfgp] + [_P] * 16,
         "tt_points_bwd_geo": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P, _P, _wp, _P],
         "tt_points_bwd_tex": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _I32, _I32, _P, _P, _wp, _P],
+        "tt_points_bwd_x": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _P, _P, _P],
         "tt_hashgrid_n_params": [ctypes.POINTER(HashGridCfg)],
         "tt_hashgrid_fwd": [_P, _I64, _P, ctypes.POINTER(HashGridCfg), _P, _P],
         "tt_hashgrid_bwd": [_P, _I64, _P, ctypes.POINTER(HashGridCfg), _P, _P],

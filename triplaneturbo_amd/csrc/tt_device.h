@@ -190,6 +190,7 @@ struct Corners {
     float dv[4];  // d w / d iy
     int hs[4];    // 8x8 torus hash of the texel (y&7)*8 + (x&7): slot in the write-combining window
     bool any;     // any corner in bounds
+    int inmask;   // bit k: corner k in bounds (d2 w_k / d ix d iy = +1, -1, -1, +1 there, 0 elsewhere)
 };
 
 #pragma clang fp contract(off)
@@ -226,6 +227,7 @@ __device__ __forceinline__ void corners_setup(float gx, float gy, int H, int W, 
     c.hs[2] = (((y0 + 1) & 7) << 3) | (x0 & 7);
     c.hs[3] = (((y0 + 1) & 7) << 3) | ((x0 + 1) & 7);
     c.any = in0 || in1 || in2 || in3;
+    c.inmask = (in0 ? 1 : 0) | (in1 ? 2 : 0) | (in2 ? 4 : 0) | (in3 ? 8 : 0);
 }
 
 // world position -> plane-sampling coordinates, mirroring the reference's fp32 op order:

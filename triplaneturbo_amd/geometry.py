@@ -117,13 +117,15 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
     def forward(self, points: Tensor, space_cache: Tensor, output_normal: bool = False) -> Dict[str, Tensor]:
         """few_step...:273-351.  points (B,N,3); space_cache (P,6,32,H,W) with B a multiple of P (view b reads
         prompt b // (B/P)).  Under autograd (training-time per-point decode, e.g. the raster path
-        generative_space_mesh_rasterize_renderer.py:321-376) the outputs are connected to space_cache and the MLP
-        weights, second order through sdf_grad included; the points themselves are constants."""
+        generative_space_mesh_rasterize_renderer.py:321-376) the outputs are connected to space_cache, the MLP weights
+        and -- if they require grad, like positions interpolated from mesh vertices (:307-331) -- the points, second
+        order through sdf_grad included."""
         B, N, _ = points.shape
         P = space_cache.shape[0]
         sw, fw = self.mlp_weights()
-        pts = points.detach().float()
-        if self._wants_grad(space_cache, (sw, fw)):
+        pts_grad = torch.is_grad_enabled() and points.requires_grad
+        pts = points.float() if pts_grad else points.detach().float()
+        if pts_grad or self._wants_grad(space_cache, (sw, fw)):
             sdf, grad, feat = ops.query_points_grad(space_cache, sw, fw, pts, views_per_prompt=B // P,
                                                     radius=self.cfg.radius,
                                                     sdf_bias_radius=float(self.cfg.sdf_bias_params),
@@ -135,7 +137,7 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
                                                    views_per_prompt=B // P, radius=self.cfg.radius,
                                                    sdf_bias_radius=float(self.cfg.sdf_bias_params),
                                                    need_normal=output_normal, need_features=True)
-        bias = (points.reshape(-1, 3) ** 2).sum(-1, keepdim=True).sqrt() - float(self.cfg.sdf_bias_params)
+        bias = (pts.reshape(-1, 3) ** 2).sum(-1, keepdim=True).sqrt() - float(self.cfg.sdf_bias_params)
         out = {"sdf": sdf, "sdf_orig": sdf - bias, "features": feat}
         if output_normal:
             normal = torch.nn.functional.normalize(grad, dim=-1)

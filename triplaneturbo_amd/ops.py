@@ -197,8 +197,10 @@ def query_field(packed: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tens
 class _QueryPointsFn(torch.autograd.Function):
     """Differentiable per-point decode (geometry.forward in training, few_step...:273-351): forward =
     tt_planes_pack + tt_query_points, backward = tt_points_bwd_geo (sdf and, through the second-order chain,
-    sdf_grad) + tt_points_bwd_tex (features) + tt_planes_unpack_grad.  Differentiable inputs: space_cache and the
-    six MLP matrices; the points are constants."""
+    sdf_grad) + tt_points_bwd_tex (features) + tt_planes_unpack_grad, and tt_points_bwd_x for the query points.
+    Differentiable inputs: space_cache, the six MLP matrices and the points (the reference keeps `points` in the
+    graph: the raster renderer decodes positions interpolated from mesh vertices,
+    generative_space_mesh_rasterize_renderer.py:307-331)."""
 
     @staticmethod
     def forward(ctx, space_cache, w1, w2, w3, v1, v2, v3, points, views_per_prompt, radius, sdf_bias_radius,
@@ -222,31 +224,41 @@ class _QueryPointsFn(torch.autograd.Function):
         B, N, _ = points.shape
         P, _, H, W, _ = packed.shape
         wst, keep = _weights_struct((w1, w2, w3), (v1, v2, v3))
-        grad_packed = torch.zeros_like(packed)
-        gw = [torch.zeros_like(t) for t in (w1, w2, w3, v1, v2, v3)]
-        gst = _grads_struct(gw)
         lib = _lib.load()
         c = lambda t: None if t is None else t.contiguous()
         g_sdf, g_grad, g_feat = c(g_sdf), c(g_grad), c(g_feat)
-        if g_sdf is not None or g_grad is not None:
-            ws = torch.empty((B * N, 4), device=packed.device, dtype=torch.float32)
-            st = lib.tt_points_bwd_geo(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius,
-                                       bias_r, 0, _ptr(g_sdf), _ptr(g_grad), _ptr(ws), _ptr(grad_packed),
-                                       ctypes.byref(gst), _stream())
-            _lib.check(st, "tt_points_bwd_geo")
-        if g_feat is not None:
-            st = lib.tt_points_bwd_tex(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius, 3,
-                                       0, _ptr(g_feat), _ptr(grad_packed), ctypes.byref(gst), _stream())
-            _lib.check(st, "tt_points_bwd_tex")
-        g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
-        return (g_cache, *gw, None, None, None, None, None)
+        gw = [None] * 6
+        g_cache = None
+        if any(ctx.needs_input_grad[:7]):
+            grad_packed = torch.zeros_like(packed)
+            gw = [torch.zeros_like(t) for t in (w1, w2, w3, v1, v2, v3)]
+            gst = _grads_struct(gw)
+            if g_sdf is not None or g_grad is not None:
+                ws = torch.empty((B * N, 4), device=packed.device, dtype=torch.float32)
+                st = lib.tt_points_bwd_geo(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius,
+                                           bias_r, 0, _ptr(g_sdf), _ptr(g_grad), _ptr(ws), _ptr(grad_packed),
+                                           ctypes.byref(gst), _stream())
+                _lib.check(st, "tt_points_bwd_geo")
+            if g_feat is not None:
+                st = lib.tt_points_bwd_tex(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius,
+                                           3, 0, _ptr(g_feat), _ptr(grad_packed), ctypes.byref(gst), _stream())
+                _lib.check(st, "tt_points_bwd_tex")
+            g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
+        g_points = None
+        if ctx.needs_input_grad[7]:
+            g_points = torch.empty_like(points)
+            st = lib.tt_points_bwd_x(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius, 0,
+                                     _ptr(g_sdf), _ptr(g_grad), _ptr(g_feat), _ptr(g_points), _stream())
+            _lib.check(st, "tt_points_bwd_x")
+        return (g_cache, *gw, g_points, None, None, None, None)
 
 
 def query_points_grad(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], points: Tensor,
                       views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5,
                       need_normal: bool = True):
     """Differentiable per-point decode: sdf (B*N,1), sdf_grad (B*N,3) (zeros, non-differentiable, when
-    need_normal is False), features (B*N,3); autograd-connected to space_cache and the six MLP matrices."""
+    need_normal is False), features (B*N,3); autograd-connected to space_cache, the six MLP matrices and -- when
+    `points` requires grad -- the points."""
     return _QueryPointsFn.apply(space_cache, sdf_w[0], sdf_w[1], sdf_w[2], feat_w[0], feat_w[1], feat_w[2],
                                 _chk(points, "points"), int(views_per_prompt), float(radius), float(sdf_bias_radius),
                                 bool(need_normal))
