@@ -45,6 +45,7 @@
  *   tt_points_bwd_geo /     the autograd backward of tt_query_points / tt_query_field w.r.t. planes and MLP weights
  *   tt_points_bwd_tex       (training-time callers: generative_space_mesh_rasterize_renderer.py:428-452 field
  *                           query, :321-376 per-pixel geometry decode); same kernels as tt_render_bwd_*.
+ *   tt_patch_composite_*    PatchRenderer.forward's upsample + paste per output key (patch_renderer.py:74-88)
  *   tt_hashgrid_fwd / _bwd  tiny-cuda-nn's `HashGrid` encoding as used by the background
  *                           (multi_prompt_neural_environment_hashgrid_map_background.py:25-34,54,104-105 via
  *                           threestudio/models/networks.py:17-26,54-64); tcnn is CUDA-only and un-vendored.
@@ -273,6 +274,15 @@ int tt_hashgrid_fwd(const float* x, int64_t n, const float* params, const tt_has
                     void* stream);
 int tt_hashgrid_bwd(const float* x, int64_t n, const float* g_out, const tt_hashgrid_cfg* cfg, float* grad_params,
                     void* stream);
+
+/* PatchRenderer's per-key composite (threestudio/models/renderers/patch_renderer.py:74-88): out (B,H,W,C) = bilinear
+ * upsample (F.interpolate, align_corners=False) of low (B,h,w,C) with patch (B,PS,PS,C) pasted at rows py.., columns
+ * px..  _bwd: g_patch = the pasted region of g_out; g_low = the adjoint of the upsample over the pixels the patch did
+ * not overwrite (null = global_detach: skipped).  Both overwrite their outputs. */
+int tt_patch_composite_fwd(const float* low, const float* patch, float* out, int32_t B, int32_t h, int32_t w, int32_t H,
+                           int32_t W, int32_t C, int32_t PS, int32_t py, int32_t px, void* stream);
+int tt_patch_composite_bwd(const float* g_out, float* g_low, float* g_patch, int32_t B, int32_t h, int32_t w, int32_t H,
+                           int32_t W, int32_t C, int32_t PS, int32_t py, int32_t px, void* stream);
 
 /* Operator-level drop-in for the reference's pybind op `gridsample_grad2.grad2_2d`
  * (gridsample_cuda.cpp:26-37): backward of aten::grid_sampler_2d_backward, bilinear.  Contiguous fp32:

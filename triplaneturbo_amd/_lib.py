@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libtt_hip.so")
 # dev-only variant built with -DTT_TUNING: honours the TT_DEBUG_FLAGS / TT_SB / TT_CHUNK / TT_UNIT / TT_ORDER
 # environment variables (profiling ablations and tuning sweeps, tools/).  The product library above never calls getenv.
 TUNING_LIB_PATH = os.path.join(_HERE, "libtt_hip_tuning.so")
-SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_points.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
+SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_points.hip", "tt_composite.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared", "-fno-gpu-rdc"]
 
 # every symbol include/tt_abi.h declares (tests check the header and this list agree)
@@ -27,7 +27,7 @@ SYMBOLS = [
     "tt_query_field", "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2",
     "tt_march_fwd", "tt_march_bwd", "tt_sample_uniform", "tt_sample_importance",
     "tt_points_bwd_geo", "tt_points_bwd_tex", "tt_points_bwd_x", "tt_hashgrid_n_params", "tt_hashgrid_fwd", "tt_hashgrid_bwd",
-    "tt_debug_poison_queue",
+    "tt_debug_poison_queue", "tt_patch_composite_fwd", "tt_patch_composite_bwd",
 ]
 
 
@@ -154,6 +154,8 @@ def load() -> ctypes.CDLL:
         "tt_sample_importance": [_P, _P, _P, _I64, _I32, _I32, _F, _F, _P, _P, _P, _P],
         "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
         "tt_debug_poison_queue": [_P],
+        "tt_patch_composite_fwd": [_P, _P, _P] + [_I32] * 9 + [_P],
+        "tt_patch_composite_bwd": [_P, _P, _P] + [_I32] * 9 + [_P],
     }
     for name, argtypes in optional.items():
         if name in SYMBOLS:

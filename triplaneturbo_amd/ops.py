@@ -568,3 +568,41 @@ def decode_rays(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Sequen
                                         _stream())
     _lib.check(st, "tt_decode_rays")
     return sdf, grad, feat
+
+
+class _PatchCompositeFn(torch.autograd.Function):
+    """tt_patch_composite_fwd / _bwd: bilinear upsample of the low-resolution global render + paste of the patch
+    (patch_renderer.py:74-88) as one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, low, patch, py, px, H, W, detach_low):
+        low, patch = _chk(low, "low"), _chk(patch, "patch")
+        B, h, w, C = low.shape
+        PS = patch.shape[1]
+        if patch.shape != (B, PS, PS, C):
+            raise ValueError(f"patch {tuple(patch.shape)} does not match low {tuple(low.shape)}")
+        out = torch.empty((B, H, W, C), device=low.device, dtype=torch.float32)
+        st = _lib.load().tt_patch_composite_fwd(_ptr(low), _ptr(patch), _ptr(out), B, h, w, H, W, C, PS, py, px,
+                                                _stream())
+        _lib.check(st, "tt_patch_composite_fwd")
+        ctx.meta = (B, h, w, H, W, C, PS, py, px, detach_low)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out):
+        B, h, w, H, W, C, PS, py, px, detach_low = ctx.meta
+        g_out = g_out.contiguous()
+        want_low = ctx.needs_input_grad[0] and not detach_low
+        g_low = torch.empty((B, h, w, C), device=g_out.device, dtype=torch.float32) if want_low else None
+        g_patch = torch.empty((B, PS, PS, C), device=g_out.device, dtype=torch.float32)
+        st = _lib.load().tt_patch_composite_bwd(_ptr(g_out), _ptr(g_low), _ptr(g_patch), B, h, w, H, W, C, PS, py, px,
+                                                _stream())
+        _lib.check(st, "tt_patch_composite_bwd")
+        return g_low, (g_patch if ctx.needs_input_grad[1] else None), None, None, None, None, None
+
+
+def patch_composite(low: Tensor, patch: Tensor, py: int, px: int, H: int, W: int, detach_low: bool = False) -> Tensor:
+    """(B,h,w,C) low-resolution image upsampled bilinearly (align_corners=False) to (B,H,W,C) with `patch`
+    (B,PS,PS,C) pasted at rows py.., columns px..; differentiable w.r.t. both (low: unless detach_low)."""
+    return _PatchCompositeFn.apply(low, patch, int(py), int(px), int(H), int(W), bool(detach_low))

@@ -270,16 +270,12 @@ class PatchRenderer(BaseModule):
         detach = self.cfg.global_detach
 
         def composite(low: Tensor, patch: Tensor):
-            # bilinear upsample of the global render + paste of the patch (patch_renderer.py:74-88); evaluated when the
-            # key is first read: a loss reads a few of the ~10 image-shaped outputs, the reference upsamples all of them
+            # bilinear upsample of the global render + paste of the patch (patch_renderer.py:74-88) as ONE HIP kernel
+            # (tt_patch_composite_fwd; its backward is one more), evaluated when the key is first read: a loss reads a
+            # few of the ~10 image-shaped outputs, the reference upsamples all of them with six torch ops each
             def run():
                 with torch.set_grad_enabled(grad_mode):
-                    up = F.interpolate(low.permute(0, 3, 1, 2), (H, W), mode="bilinear").permute(0, 2, 3, 1)
-                    if detach:
-                        up = up.detach()
-                    up = up.clone()
-                    up[:, py:py + PS, px:px + PS] = patch
-                    return up
+                    return ops.patch_composite(low, patch, py, px, H, W, detach_low=detach)
             return run
 
         if not isinstance(out_global, functional.LazyOutputs):
