@@ -33,6 +33,8 @@
  *                           generative_space_sdf_volume_renderer.py:326-431,467-472 (positions, geometry,
  *                           NoMaterial no_material.py:41-54, get_alpha neus_volume_renderer.py:93-117,
  *                           nerfacc.render_weight_from_alpha, nerfacc.accumulate_along_rays x5).
+ *   tt_render_eval          the same in eval mode (per-ray outputs only): decode + march fused per ray tile with
+ *                           wave-ballot early termination / texture-decode skipping
  *   tt_march_fwd / _bwd     the ray march alone (second half of tt_render_fwd / first half of tt_render_bwd_geo):
  *                           get_alpha neus_volume_renderer.py:93-117 + nerfacc.render_weight_from_alpha +
  *                           nerfacc.accumulate_along_rays x5 (renderer :407-431,467-472) on given per-sample
@@ -191,6 +193,18 @@ int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const float* ray
                   const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, float* opacity, float* depth,
                   float* rgb_fg, float* z_variance, float* normal_acc, float* weights, float* trans, float* sdf,
                   float* sdf_grad, float* features, void* stream);
+
+/* Eval-mode render (the renderer returns no per-sample tensors outside training, renderer :532-545): the per-ray outputs
+ * of tt_render_fwd from ONE kernel that decodes and marches each 8x4-pixel ray tile front to back.
+ * transmittance_eps > 0: a ray stops contributing once its transmittance is below it and a tile stops when all its rays
+ * have (wave ballot); weight_eps > 0: the texture decode of a tile step is skipped unless some ray has a larger weight,
+ * and runs for those rays only.  Induced error: opacity / rgb < transmittance_eps + S * weight_eps per ray (depth: x far).
+ * Both 0: no approximation (the skips that remain are exact).  stats (device, 2 x uint64, may be null; caller zero-fills):
+ * += wave tile steps with a geometry decode / with a texture decode.  No gradients: eval only. */
+int tt_render_eval(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
+                   const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, float transmittance_eps,
+                   float weight_eps, float* opacity, float* depth, float* rgb_fg, float* z_variance, float* normal_acc,
+                   uint64_t* stats, void* stream);
 
 /* The ray march alone, on per-sample sdf (n_rays*S), sdf_grad (.,3), features (.,3) that the caller already has
  * (tt_decode_rays / tt_query_points): per-ray and per-sample outputs as in tt_render_fwd. */

@@ -36,6 +36,7 @@ def _weights(g):
 def test_eval_render_matches_oracle_and_keys(dev):
     g, m, b, r, cfg = _build(dev)
     r.eval()
+    r.eval_termination_eps = 0.0  # parity: march every sample like the reference (tests/test_gpu_eval.py covers > 0)
     gen = torch.Generator().manual_seed(1)
     P, n_view, Hh, Ww = 1, 2, 6, 8
     cache = torch.randn(P, 6, 32, 32, 32, generator=gen) * 0.5

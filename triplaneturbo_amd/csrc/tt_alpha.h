@@ -1,0 +1,33 @@
+// tt_alpha.h -- NeuS alpha of one sample (threestudio/models/renderers/neus_volume_renderer.py:93-117) and the fast
+// logistic it is built on; shared by the ray-march kernels (tt_march.hip) and the fused eval render (tt_forward.hip).
+#pragma once
+#include "tt_device.h"
+
+struct AlphaTerms {
+    float alpha, rat, den, sA, sB, half, dic_dcos;
+    bool pass;
+};
+
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }  // 1 ulp
+// logistic function on the hardware exp2 / rcp (2 + 2 instructions instead of ~25 for 1 / (1 + expf(-x)) with the
+// IEEE division): relative error ~|x| 2^-24 from the rounded x log2(e), i.e. <= 1e-6 wherever the result is not
+// saturated; overflow of exp2 for x < -88 gives rcp(inf) = 0 like the reference
+__device__ __forceinline__ float sigmoid_(float x) { return rcp_(1.f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
+
+// neus_volume_renderer.py:98-116 (use_volsdf = False)
+__device__ __forceinline__ AlphaTerms neus_alpha_terms(float sdf, float cosv, float dt, float kstd, float ratio) {
+    AlphaTerms a;
+    const float c1 = -cosv * 0.5f + 0.5f, c2 = -cosv;
+    const float ic = -(fmaxf(c1, 0.f) * (1.f - ratio) + fmaxf(c2, 0.f) * ratio);
+    a.dic_dcos = (c1 > 0.f ? 0.5f * (1.f - ratio) : 0.f) + (c2 > 0.f ? ratio : 0.f);
+    a.half = dt * 0.5f;
+    const float next_sdf = sdf + ic * a.half, prev_sdf = sdf - ic * a.half;
+    a.sA = sigmoid_(prev_sdf * kstd);
+    a.sB = sigmoid_(next_sdf * kstd);
+    a.den = a.sA + 1e-5f;
+    a.rat = ((a.sA - a.sB) + 1e-5f) * rcp_(a.den);
+    a.alpha = fminf(fmaxf(a.rat, 0.f), 1.f);
+    a.pass = a.rat >= 0.f && a.rat <= 1.f;
+    return a;
+}
+

@@ -1,6 +1,7 @@
 // tt_forward.hip -- plane pack/unpack, per-point decode (tt_query_points) and the fused forward render.
 #include "tt_device.h"
 #include "tt_mfma16.h"
+#include "tt_alpha.h"
 #include "tt_host.h"
 
 #include <stdlib.h>
@@ -82,84 +83,95 @@ struct DecodeCfg {
 #define OFF_W2T (OFF_W1T + IMG16_FLOATS(32, 64))
 #define LDS_W16_FLOATS (OFF_W2T + IMG16_FLOATS(64, 64))
 
+// texture half: e -> feature net -> c (3 raw features).  Lanes with !valid gather nothing (their c is 0).
+template <bool EXACT>
+__device__ __forceinline__ void decode_tex_fwd(const float* L, const DecodeCfg& dc, float X, float Y, float Z,
+                                               bool valid, int i, int hi, float (&c)[3]) {
+    c[0] = c[1] = c[2] = 0.f;
+    float e[48];
+    bool any = gather_tex(dc.pbase, dc.H, dc.W, X, Y, Z, valid, hi, e, dc.dbg);
+    if (TT_DBG(dc.dbg, TT_DBG_NO_MLP)) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 48; ++r) t += e[r];
+        c[0] = c[1] = c[2] = t;
+    } else if (__any(any)) {  // exact skip: e == 0 for the whole tile => features == 0 (bias-free MLP)
+        float k1[32], k2[32];
+        mvx<EXACT, 64, 96>(L + OFF_V1, e, k1, i, hi);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
+        mvx<EXACT, 64, 64>(L + OFF_V2, k1, k2, i, hi);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) k2[r] = fmaxf(k2[r], 0.f);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) c[o] = dot_lds<64>(L + OFF_V3 + 64 * o, k2, hi);
+    }
+}
+
+// geometry half: f (+ J) -> sdf net -> s0 and, if NEED_N, gq = J^T q (WITHOUT the sphere term)
+template <bool NEED_N, bool EXACT>
+__device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& dc, float X, float Y, float Z,
+                                               bool valid, int i, int hi, float& s0, float (&gq)[3]) {
+    s0 = 0.f;
+    gq[0] = gq[1] = gq[2] = 0.f;
+    float f[16], jx[16], jy[16], jz[16];
+    bool any = gather_geo<NEED_N>(dc.pbase, dc.H, dc.W, X, Y, Z, valid, dc.ju, dc.jv, hi, f, jx, jy, jz, dc.dbg);
+    if (TT_DBG(dc.dbg, TT_DBG_NO_MLP)) {
+        float t = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            t += f[r];
+            tx += jx[r];
+            ty += jy[r];
+            tz += jz[r];
+        }
+        s0 = t;
+        gq[0] = tx;
+        gq[1] = ty;
+        gq[2] = tz;
+    } else if (__any(any)) {
+        float h1[32], h2[32];
+        mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
+        mvx<EXACT, 64, 64>(L + OFF_W2, h1, h2, i, hi);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
+        s0 = dot_lds<64>(L + OFF_W3, h2, hi);
+        if (NEED_N) {
+            // reverse-mode input gradient: a2 = m2 . w3 ; a1 = m1 . (W2^T a2) ; q = W1^T a1
+            float a2[32], a1[32], q[16];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                f32x4 w3 = *reinterpret_cast<const f32x4*>(L + OFF_W3 + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
+            }
+            mvtx<EXACT, 64, 64>(L + OFF_W2T, L + OFF_W2, a2, a1, i, hi);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
+            mvtx<EXACT, 32, 64>(L + OFF_W1T, L + OFF_W1, a1, q, i, hi);
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sx = fmaf(q[r], jx[r], sx);
+                sy = fmaf(q[r], jy[r], sy);
+                sz = fmaf(q[r], jz[r], sz);
+            }
+            gq[0] = sx + __shfl_xor(sx, 32);
+            gq[1] = sy + __shfl_xor(sy, 32);
+            gq[2] = sz + __shfl_xor(sz, 32);
+        }
+    }
+}
+
 template <bool NEED_N, bool NEED_TEX, bool EXACT>
 __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, float px, float py, float pz,
                                            bool valid, int i, int hi, float& s0, float (&gq)[3], float (&c)[3]) {
     const float X = scale_coord(px, dc.radius), Y = scale_coord(py, dc.radius), Z = scale_coord(pz, dc.radius);
-    s0 = 0.f;
-    gq[0] = gq[1] = gq[2] = 0.f;
     c[0] = c[1] = c[2] = 0.f;
-    if (NEED_TEX) {
-        float e[48];
-        bool any = gather_tex(dc.pbase, dc.H, dc.W, X, Y, Z, valid, hi, e, dc.dbg);
-        if (TT_DBG(dc.dbg, TT_DBG_NO_MLP)) {
-            float t = 0.f;
-#pragma unroll
-            for (int r = 0; r < 48; ++r) t += e[r];
-            c[0] = c[1] = c[2] = t;
-        } else if (__any(any)) {  // exact skip: e == 0 for the whole tile => features == 0 (bias-free MLP)
-            float k1[32], k2[32];
-            mvx<EXACT, 64, 96>(L + OFF_V1, e, k1, i, hi);
-#pragma unroll
-            for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
-            mvx<EXACT, 64, 64>(L + OFF_V2, k1, k2, i, hi);
-#pragma unroll
-            for (int r = 0; r < 32; ++r) k2[r] = fmaxf(k2[r], 0.f);
-#pragma unroll
-            for (int o = 0; o < 3; ++o) c[o] = dot_lds<64>(L + OFF_V3 + 64 * o, k2, hi);
-        }
-    }
-    {
-        float f[16], jx[16], jy[16], jz[16];
-        bool any = gather_geo<NEED_N>(dc.pbase, dc.H, dc.W, X, Y, Z, valid, dc.ju, dc.jv, hi, f, jx, jy, jz, dc.dbg);
-        if (TT_DBG(dc.dbg, TT_DBG_NO_MLP)) {
-            float t = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                t += f[r];
-                tx += jx[r];
-                ty += jy[r];
-                tz += jz[r];
-            }
-            s0 = t;
-            gq[0] = tx;
-            gq[1] = ty;
-            gq[2] = tz;
-        } else if (__any(any)) {
-            float h1[32], h2[32];
-            mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
-#pragma unroll
-            for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mvx<EXACT, 64, 64>(L + OFF_W2, h1, h2, i, hi);
-#pragma unroll
-            for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
-            s0 = dot_lds<64>(L + OFF_W3, h2, hi);
-            if (NEED_N) {
-                // reverse-mode input gradient: a2 = m2 . w3 ; a1 = m1 . (W2^T a2) ; q = W1^T a1
-                float a2[32], a1[32], q[16];
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    f32x4 w3 = *reinterpret_cast<const f32x4*>(L + OFF_W3 + 8 * g + 4 * hi);
-#pragma unroll
-                    for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
-                }
-                mvtx<EXACT, 64, 64>(L + OFF_W2T, L + OFF_W2, a2, a1, i, hi);
-#pragma unroll
-                for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-                mvtx<EXACT, 32, 64>(L + OFF_W1T, L + OFF_W1, a1, q, i, hi);
-                float sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sx = fmaf(q[r], jx[r], sx);
-                    sy = fmaf(q[r], jy[r], sy);
-                    sz = fmaf(q[r], jz[r], sz);
-                }
-                gq[0] = sx + __shfl_xor(sx, 32);
-                gq[1] = sy + __shfl_xor(sy, 32);
-                gq[2] = sz + __shfl_xor(sz, 32);
-            }
-        }
-    }
+    if (NEED_TEX) decode_tex_fwd<EXACT>(L, dc, X, Y, Z, valid, i, hi, c);
+    decode_geo_fwd<NEED_N, EXACT>(L, dc, X, Y, Z, valid, i, hi, s0, gq);
 }
 
 // =====================================================================================================
@@ -404,6 +416,129 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
                 }
             }
         }
+    }
+}
+
+// =====================================================================================================
+// Fused EVAL render: decode + march per ray tile, front to back, with ballot-based early exit
+// =====================================================================================================
+// In eval mode the renderer returns per-ray outputs only (renderer :532-545 adds the per-sample extras in training
+// only), so nothing forces every sample to be decoded: a wave owns 32 ADJACENT RAYS (an 8x4 pixel block; lane <-> ray,
+// both half-waves carry the same ray state) and walks them front to back, one sample index per step:
+//   geometry decode (+ normal) -> NeuS alpha -> w = alpha T, T *= 1 - alpha          (no scan: a lane IS a ray)
+//   texture decode only if ANY ray of the tile has w > eps_w (wave ballot), and only for those lanes
+//   stop when EVERY ray of the tile has T < eps_T                                     (wave ballot)
+// Induced error: the dropped weights of a ray sum to < eps_T (opacity, rgb; depth x far), the skipped colours to
+// < S eps_w.  eps_T = eps_w = 0 disables both and reproduces tt_render_fwd's per-ray outputs (parity tests); nothing
+// per-sample is written, which alone removes the 0.5 GB of per-sample traffic and the separate march kernel.
+struct RenderEvalParams {
+    const float* packed;
+    MlpPtrs w;
+    const float* rays_o;
+    const float* rays_d;
+    const float* t_starts;
+    const float* t_ends;
+    tt_render_cfg cfg;
+    TileGeom geom;
+    int* queue;
+    float eps_T, eps_w;
+    float* opacity;
+    float* depth;
+    float* rgb_fg;
+    float* z_var;
+    float* nacc;
+    unsigned long long* stats;  // [0] += tile steps decoded, [1] += tile steps with a texture decode (may be null)
+};
+
+template <bool EXACT>
+__global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams p) {
+    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS];
+    stage_decode_images<true, true, EXACT>(L, p.w);
+    __syncthreads();
+    const tt_render_cfg& cfg = p.cfg;
+    const TileGeom& tg = p.geom;
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const int S = cfg.n_samples;
+    ItemQueue iq = item_queue(p.queue, tg.n_blocks, 1, tg.unit);
+    const size_t plane_stride = (size_t)6 * cfg.plane_h * cfg.plane_w * TT_C;
+    unsigned long long n_geo = 0, n_tex = 0;
+#pragma nounroll
+    for (;;) {
+        long long b;
+        int ck;
+        if (!item_pop(iq, 1, 1, b, ck)) break;
+        if (b >= tg.n_blocks) continue;
+        bool ray_ok;
+        const long long ray = tile_ray(tg, b, i, ray_ok);
+        const int view = (int)(ray / cfg.rays_per_view);
+        DecodeCfg dc;
+        dc.pbase = p.packed + (size_t)(view / cfg.views_per_prompt) * plane_stride;
+        dc.H = cfg.plane_h;
+        dc.W = cfg.plane_w;
+        dc.radius = cfg.radius;
+        dc.ju = 0.5f * cfg.plane_w / cfg.radius;
+        dc.jv = 0.5f * cfg.plane_h / cfg.radius;
+        dc.dbg = 0;
+        const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
+        const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
+        float T = 1.f, op = 0.f, dep = 0.f, wt2 = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+#pragma nounroll
+        for (int si = 0; si < S; ++si) {
+            const long long sidx = ray * S + si;
+            const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
+            float tm, px, py, pz;
+            sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
+            const float X = scale_coord(px, dc.radius), Y = scale_coord(py, dc.radius), Z = scale_coord(pz, dc.radius);
+            const bool live = ray_ok && !(T < p.eps_T);  // (eps_T = 0: always live)
+            float s0, gq[3];
+            decode_geo_fwd<true, EXACT>(L, dc, X, Y, Z, live, i, hi, s0, gq);
+            ++n_geo;
+            float nrm;
+            const float sdf = s0 + sphere_bias(px, py, pz, cfg.sdf_bias_radius, nrm);
+            const float gx = gq[0] + px / nrm, gy = gq[1] + py / nrm, gz = gq[2] + pz / nrm;
+            const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps
+            const float ign = rcp_(gn);
+            const float ux = gx * ign, uy = gy * ign, uz = gz * ign;
+            const float cosv = dx * ux + dy * uy + dz * uz;
+            float alpha = neus_alpha_terms(sdf, cosv, te - ts, cfg.inv_std, cfg.cos_anneal_ratio).alpha;
+            if (!live) alpha = 0.f;
+            const float wgt = alpha * T;
+            T *= 1.f - alpha;
+            op += wgt;
+            dep = fmaf(wgt, tm, dep);
+            wt2 = fmaf(wgt * tm, tm, wt2);
+            nx = fmaf(wgt, ux, nx);
+            ny = fmaf(wgt, uy, ny);
+            nz = fmaf(wgt, uz, nz);
+            const bool want_tex = live && wgt > p.eps_w;  // (eps_w = 0: every sample with a non-zero weight)
+            if (__any(want_tex)) {
+                float c[3];
+                decode_tex_fwd<EXACT>(L, dc, X, Y, Z, want_tex, i, hi, c);
+                ++n_tex;
+                if (want_tex) {  // NoMaterial + sigmoid-mipnerf (no_material.py:41-54, ops.py:118-119)
+                    cr = fmaf(wgt, sigmoid_(c[0]) * 1.002f - 0.001f, cr);
+                    cg = fmaf(wgt, sigmoid_(c[1]) * 1.002f - 0.001f, cg);
+                    cb = fmaf(wgt, sigmoid_(c[2]) * 1.002f - 0.001f, cb);
+                }
+            }
+            if (p.eps_T > 0.f && !__any(ray_ok && !(T < p.eps_T))) break;  // every ray of the tile is opaque
+        }
+        if (ray_ok && hi == 0) {
+            p.opacity[ray] = op;
+            p.depth[ray] = dep;
+            p.rgb_fg[ray * 3 + 0] = cr;
+            p.rgb_fg[ray * 3 + 1] = cg;
+            p.rgb_fg[ray * 3 + 2] = cb;
+            // z_variance = sum w (t - D)^2 with D = sum w t  (renderer :424-431)  =  sum w t^2 - 2 D^2 + D^2 sum w
+            p.z_var[ray] = wt2 - 2.f * dep * dep + dep * dep * op;
+            p.nacc[ray * 3 + 0] = nx;
+            p.nacc[ray * 3 + 1] = ny;
+            p.nacc[ray * 3 + 2] = nz;
+        }
+    }
+    if (p.stats && lane == 0) {
+        atomicAdd(p.stats + 0, n_geo);
+        atomicAdd(p.stats + 1, n_tex);
     }
 }
 
@@ -720,5 +855,55 @@ extern "C" int tt_query_field(const float* packed, const tt_mlp_weights* w, cons
         hipLaunchKernelGGL(k_query_field<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(k_query_field<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return tt_check_launch();
+}
+
+
+// Eval-mode render: per-ray outputs only, decode and march fused per ray tile, optional early termination.
+extern "C" int tt_render_eval(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
+                              const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,
+                              float transmittance_eps, float weight_eps, float* opacity, float* depth, float* rgb_fg,
+                              float* z_variance, float* normal_acc, uint64_t* stats, void* stream) {
+    int st = tt_validate_cfg(cfg);
+    if (st != TT_OK) return st;
+    if (!packed || !w || !rays_o || !rays_d || !t_starts || !t_ends || !opacity || !depth || !rgb_fg || !z_variance ||
+        !normal_acc)
+        return TT_ERR_BAD_ARG;
+    if (!w->w1 || !w->w2 || !w->w3 || !w->v1 || !w->v2 || !w->v3) return TT_ERR_BAD_ARG;
+    if (!(transmittance_eps >= 0.f) || !(weight_eps >= 0.f)) return TT_ERR_BAD_ARG;
+    int cus = tt_num_cus();
+    if (cus <= 0) return TT_ERR_DEVICE;
+    RenderEvalParams p;
+    p.packed = packed;
+    p.w = to_ptrs(w);
+    p.rays_o = rays_o;
+    p.rays_d = rays_d;
+    p.t_starts = t_starts;
+    p.t_ends = t_ends;
+    p.cfg = *cfg;
+    p.cfg.tile_sb = 1;                     // a lane is a ray: 8x4 pixel blocks, one sample index per step
+    p.cfg.tile_chunk = cfg->n_samples;     // one work item per ray block (the march is sequential in depth)
+    p.eps_T = transmittance_eps;
+    p.eps_w = weight_eps;
+    p.opacity = opacity;
+    p.depth = depth;
+    p.rgb_fg = rgb_fg;
+    p.z_var = z_variance;
+    p.nacc = normal_acc;
+    p.stats = (unsigned long long*)stats;
+    const long long slots = (long long)cus * (DECODE_THREADS / 64);
+    const long long n_items = tt_make_geom(&p.cfg, slots, &p.geom, 1);
+    if (p.geom.n_chunks != 1 || n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
+    long long blocks = cus;
+    const long long need = (n_items + 7) / 8;
+    if (blocks > need) blocks = need;
+    blocks = (blocks + 7) / 8 * 8;
+    hipStream_t s = (hipStream_t)stream;
+    p.queue = tt_queue_counters(s);
+    if (!p.queue) return TT_ERR_DEVICE;
+    if (cfg->flags & TT_R_EXACT_F32)
+        hipLaunchKernelGGL(k_render_eval<true>, dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
+    else
+        hipLaunchKernelGGL(k_render_eval<false>, dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
     return tt_check_launch();
 }

@@ -95,16 +95,25 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
                   rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, bg_color: Tensor, camera_distances: Tensor,
                   c2w: Tensor, rc: ops.RenderConfig, training: bool = True,
                   normal_direction: str = "camera", comp_rgb_bg: Optional[Tensor] = None,
-                  packed: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                  packed: Optional[Tensor] = None, eval_termination_eps: float = 0.0) -> Dict[str, Tensor]:
     """rays_o/rays_d (B,H,W,3); t_starts/t_ends (B*H*W, S); bg_color (3,), (B*H*W,3) or (B,H,W,3);
-    packed = ops.pack_planes(space_cache) when the caller already has it."""
+    packed = ops.pack_planes(space_cache) when the caller already has it.
+    Eval renders without autograd (training=False under no_grad) return no per-sample tensor, so they run on the fused
+    decode + march kernel (tt_render_eval); eval_termination_eps > 0 lets it stop rays whose transmittance fell below
+    it and skip texture decodes of weights below eps / S (per-ray error of opacity / rgb < 2 eps)."""
     B, Hh, Ww, _ = rays_o.shape
     n_rays = B * Hh * Ww
     S = t_starts.shape[1]
     ro = rays_o.reshape(n_rays, 3)
     rd = rays_d.reshape(n_rays, 3)
-    r = ops.render_samples(space_cache, sdf_w, feat_w, ro, rd, t_starts, t_ends, Hh * Ww, rc, image_w=Ww,
-                           packed=packed)
+    if not training and not torch.is_grad_enabled():
+        pk = packed if packed is not None else ops.planes_pack(space_cache)
+        r = ops.render_eval_raw(pk, sdf_w, feat_w, ro.contiguous(), rd.contiguous(), t_starts.contiguous(),
+                                t_ends.contiguous(), Hh * Ww, rc, image_w=Ww,
+                                transmittance_eps=eval_termination_eps, weight_eps=eval_termination_eps / max(S, 1))
+    else:
+        r = ops.render_samples(space_cache, sdf_w, feat_w, ro, rd, t_starts, t_ends, Hh * Ww, rc, image_w=Ww,
+                               packed=packed)
     opacity, depth, comp_rgb_fg, z_variance = r["opacity"], r["depth"], r["rgb_fg"], r["z_variance"]
 
     if bg_color.ndim == 1:

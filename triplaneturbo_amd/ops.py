@@ -368,6 +368,38 @@ def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
 
 
 @torch.no_grad()
+def render_eval_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor, rays_d: Tensor,
+                    t_starts: Tensor, t_ends: Tensor, rays_per_view: int, rc: RenderConfig, image_w: int = 0,
+                    transmittance_eps: float = 0.0, weight_eps: float = 0.0, stats: Optional[Tensor] = None):
+    """tt_render_eval: the per-ray outputs of render_forward_raw (opacity, depth, rgb_fg, z_variance, normal_acc) from
+    the fused decode + march kernel, no per-sample tensors, no autograd.  transmittance_eps / weight_eps > 0 switch
+    on early termination / texture-decode skipping (error < transmittance_eps + S * weight_eps per ray); `stats` (2 x
+    int64 on the device, zero-filled by the caller) receives the number of geometry / texture tile steps decoded."""
+    packed = _chk(packed, "packed")
+    rays_o, rays_d = _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d")
+    t_starts, t_ends = _chk(t_starts, "t_starts"), _chk(t_ends, "t_ends")
+    n_rays, S = t_starts.shape
+    if rays_o.shape != (n_rays, 3) or rays_d.shape != (n_rays, 3) or t_ends.shape != (n_rays, S):
+        raise ValueError("ray / interval shapes disagree")
+    cfg = _make_cfg(packed, n_rays, rays_per_view, S, rc, False, image_w)
+    wst, keep = _weights_struct(sdf_w, feat_w)
+    f32 = dict(device=packed.device, dtype=torch.float32)
+    out = {"opacity": torch.empty((n_rays, 1), **f32), "depth": torch.empty((n_rays, 1), **f32),
+           "rgb_fg": torch.empty((n_rays, 3), **f32), "z_variance": torch.empty((n_rays, 1), **f32),
+           "normal_acc": torch.empty((n_rays, 3), **f32)}
+    if stats is not None and (stats.dtype != torch.int64 or stats.numel() < 2 or not stats.is_cuda):
+        raise ValueError("stats must be a CUDA int64 tensor with 2 elements")
+    with _timed("tt_render_eval"):
+        st = _lib.load().tt_render_eval(
+            _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
+            ctypes.byref(cfg), float(transmittance_eps), float(weight_eps), _ptr(out["opacity"]), _ptr(out["depth"]),
+            _ptr(out["rgb_fg"]), _ptr(out["z_variance"]), _ptr(out["normal_acc"]),
+            ctypes.c_void_p(stats.data_ptr()) if stats is not None else ctypes.c_void_p(0), _stream())
+    _lib.check(st, "tt_render_eval")
+    return out
+
+
+@torch.no_grad()
 def sample_uniform(n_rays: int, n_samples: int, near: float, far: float, device, jitter: Optional[Tensor] = None):
     """tt_sample_uniform: level-0 intervals (n_rays, n_samples); jitter (n_rays, n_samples+1) U[0,1) => stratified."""
     device = torch.device(device)

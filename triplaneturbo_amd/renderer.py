@@ -123,6 +123,10 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         # Measured at the reference training shapes (42^2 + 40^2 rays, 193 samples): sb 1/2/4/8/16 =
         # 14.4/12.9/12.5/12.3/12.8 ms per PatchRenderer forward+backward.
         self.tile_sb_importance = 8
+        # eval renders (no autograd) stop marching a ray once its transmittance is below this and skip texture decodes
+        # of weights below eps / S (tt_render_eval): per-ray error of opacity / comp_rgb < 2 eps.  0 = march everything
+        # like the reference (renderer :317-324 keeps all samples).  Not a reference knob, so not in Config.
+        self.eval_termination_eps = 1.0e-4
 
     # ------------------------------------------------------------------------------------------
     def _inv_std_value(self) -> float:
@@ -203,7 +207,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
             out = functional.volume_render(space_cache, sw, fw, rays_o, rays_d, t_starts, t_ends, bg_color,
                                            camera_distances, c2w, rc, training=self.training,
                                            normal_direction=self.cfg.normal_direction, comp_rgb_bg=comp_rgb_bg,
-                                           packed=packed)
+                                           packed=packed, eval_termination_eps=self.eval_termination_eps)
         if self.training:
             out["inv_std"] = self.variance.inv_std
         return out
