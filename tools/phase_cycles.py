@@ -1,0 +1,51 @@
+"""Dev tool (tuning build): where do the cycles of k_decode_bwd_tex go?  s_memtime stamps between the phases of a tile
+step, summed over all waves of the bench workload.  usage: python tools/phase_cycles.py"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from triplaneturbo_amd import _lib  # noqa: E402
+
+_lib.use_tuning_build()
+import bench  # noqa: E402
+from triplaneturbo_amd import functional, ops  # noqa: E402
+
+dev = torch.device("cuda", 0)
+inp = bench.make_inputs(0, 1, dev, 1)
+rc = ops.RenderConfig()
+params = [inp["cache"]] + inp["sw"] + inp["fw"]
+
+
+def step():
+    for t in params:
+        t.grad = None
+    out = functional.volume_render(inp["cache"], inp["sw"], inp["fw"], inp["ro"], inp["rd"], inp["ts"], inp["te"],
+                                   inp["bg"], inp["cd"], inp["c2w"], rc, training=True)
+    bench.loss_fn(out, inp["proj"]).backward()
+
+
+lib = _lib.load()
+lib.tt_tuning_phase_cycles.argtypes = [ctypes.c_void_p]
+buf = (ctypes.c_uint64 * 20)()
+lib.tt_tuning_phase_cycles(buf)  # allocate + reset
+step()
+lib.tt_tuning_phase_cycles(buf)  # warm-up discarded
+n = 3
+for _ in range(n):
+    step()
+lib.tt_tuning_phase_cycles(buf)
+names = ["upstream cbar + skip test", "gather e (12 corners)", "park e in LDS", "k1 = relu(V1 e)", "k2 = relu(V2 k1)",
+         "dV3 (transpose + VALU)", "k2bar, k1bar = V2^T k2bar", "dV1 outer products", "dV2 outer products",
+         "ebar_p = V1_p^T k1bar + stage (x3)", "scatter_plane epilogue", "tail",
+         "  scatter: slot claims (LDS CAS) + M fill", "  scatter: combine GEMM M Q (fp32 MFMA)",
+         "  scatter: flush (predicated 128-byte atomics)", "  scatter: restore M / tags", "  scatter: lost-reference fallback",
+         "", "", ""]
+tot = sum(buf)
+for k, nm in enumerate(names):
+    if not nm:
+        continue
+    print(f"{nm:38s} {buf[k] / n / 1024 / 1e3:9.1f} k cycles per wave-launch   {100.0 * buf[k] / tot:5.1f} %")
+print(f"total {tot / n / 1024 / 1e6:.2f} M cycles per wave (100 MHz s_memtime ticks?)")

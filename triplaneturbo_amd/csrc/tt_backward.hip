@@ -12,10 +12,27 @@
 // Everything per-sample is RECOMPUTED from the planes; the forward saves only trans / weights / features.
 #include "tt_device.h"
 #include "tt_mfma16.h"
+#include "tt_alpha.h"
 #include "tt_host.h"
 #include <stdlib.h>
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// tuning build only: cycles per phase of the texture backward, summed over waves into p.phase_cycles[16]
+#ifdef TT_TUNING
+#define TT_PHASE(k)                                              \
+    do {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+        ph_acc[k] += t_now - ph_t;                               \
+        ph_t = t_now;                                            \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#else
+#define TT_PHASE(k) \
+    do {            \
+    } while (0)
+#endif
 #define XS 36  // row stride (floats) of the [index][sample] transposition scratch
 
 // ---- LDS transposition helpers (wave-private scratch; DS ops of one wave execute in order) ----------
@@ -51,6 +68,24 @@ __device__ __forceinline__ void wgrad(f32x16 (&acc)[NX / 32][NY / 32], const flo
 #pragma unroll
                 for (int n = 0; n < NY / 32; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[m][k], yb[n][k], acc[m][n], 0, 0, 0);
+    }
+}
+
+// one 32-row slice of the left operand: acc[n] += X[0..31, s] * Y[32n.., s]^T
+template <int NY>
+__device__ __forceinline__ void wgrad_row(f32x16 (&acc)[NY / 32], const float* Xs, const float* Ys, int i, int hi) {
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+        f32x4 yb[NY / 32];
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(Xs + i * XS + 16 * hi + 4 * t4);
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n)
+            yb[n] = *reinterpret_cast<const f32x4*>(Ys + (32 * n + i) * XS + 16 * hi + 4 * t4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int n = 0; n < NY / 32; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[k], yb[n][k], acc[n], 0, 0, 0);
     }
 }
 
@@ -100,13 +135,21 @@ __device__ __forceinline__ void scatter_clear(float* M, int lane) {
     for (int g = 0; g < MS / 4; ++g) *reinterpret_cast<f32x4*>(M + lane * MS + 4 * g) = z;
 }
 
-// One plane of one tile.  Qs[j*33 + ch]: staged per-sample vectors; vec[VOFF + r]: this lane's 16 channels of its
-// own sample (fallback path only); coef/abs_off/hs: per corner of this lane's sample.
-template <int VOFF, int VTOT>
-__device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const float* Qs, const float (&vec)[VTOT],
-                                              const float (&coef)[4], const int (&abs_off)[4], const int (&hs)[4],
-                                              float* M, int* tags, float* Ls, int i, int hi, int flags) {
-    const bool no_global = TT_DBG(flags, TT_DBG_NO_GLOBAL_ATOMIC);
+// One plane of one tile.  Qs[j*33 + ch]: staged per-sample vectors; coef/abs_off/hs: per corner of this lane's sample.
+__device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const float* Qs, const float (&coef)[4], const int (&abs_off)[4], const int (&hs)[4],
+                                              float* M, int* tags, float* Ls, int i, int hi, int flags
+#ifdef TT_TUNING
+                                              ,
+                                              unsigned long long* ph_acc = nullptr, unsigned long long* ph_tp = nullptr
+#endif
+) {
+#ifdef TT_TUNING
+    unsigned long long ph_dummy[20], ph_t0 = 0;
+    if (!ph_acc) ph_acc = ph_dummy;
+    unsigned long long& ph_t = ph_tp ? *ph_tp : ph_t0;
+#endif
+    const bool region = flags >= 0;  // always true, opaque to the compiler: see k_decode_bwd_tex
+    const bool no_global = !region || TT_DBG(flags, TT_DBG_NO_GLOBAL_ATOMIC);
     // ---- claim slots and fill M: lane (i, hi) owns corners 2hi, 2hi+1 of sample i ----
     int lost = 0, wrote = 0, mine = 0;
 #pragma unroll
@@ -125,6 +168,7 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
         }
     }
     lost |= __shfl_xor(lost, 32);
+    TT_PHASE(12);
     // ---- G = M Q on the matrix cores: the two 32-slot tiles advance as independent accumulator chains ----
     f32x4 a4[2][4];
 #pragma unroll
@@ -133,14 +177,21 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
         for (int t4 = 0; t4 < 4; ++t4)
             a4[m][t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
     f32x16 acc0 = ZERO16, acc1 = ZERO16;
-    if (!TT_DBG(flags, TT_DBG_NO_SCATTER_MFMA))
+    if (region && !TT_DBG(flags, TT_DBG_NO_SCATTER_MFMA))
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const float b = Qs[(t + 16 * hi) * 33 + i];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0][t >> 2][t & 3], b, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1][t >> 2][t & 3], b, acc1, 0, 0, 0);
     }
-    // flush: one 128-byte atomic per occupied slot, straight from the accumulators (slot of reg 4g+e = LIDX)
+    TT_PHASE(13);
+    // flush: one 128-byte atomic per occupied slot, straight from the accumulators (slot of reg 4g+e = LIDX).
+    // Addresses are a wave-uniform base plus a 32-bit BYTE offset (texel << 7 | channel * 4): one VALU instruction and
+    // the scalar-base form of the atomic instead of four instructions of 64-bit arithmetic per atomic (the host
+    // refuses gradient buffers of 4 GB and more).
+    char* const gbase = reinterpret_cast<char*>(grad);
+    const unsigned lane_b = 4u * (unsigned)i;
+#define TT_TEXEL_ADDR(T) reinterpret_cast<float*>(gbase + (((unsigned)(T) << 7) | lane_b))
     if (!no_global) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -148,17 +199,19 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
             const i32x4 k1 = *reinterpret_cast<const i32x4*>(tags + 32 + 8 * g + 4 * hi);
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) {
-                if (k0[e2] != -1) atomicAdd(grad + (size_t)k0[e2] * TT_C + i, acc0[4 * g + e2]);
-                if (k1[e2] != -1) atomicAdd(grad + (size_t)k1[e2] * TT_C + i, acc1[4 * g + e2]);
+                if (k0[e2] != -1) atomicAdd(TT_TEXEL_ADDR(k0[e2]), acc0[4 * g + e2]);
+                if (k1[e2] != -1) atomicAdd(TT_TEXEL_ADDR(k1[e2]), acc1[4 * g + e2]);
             }
         }
     }
+    TT_PHASE(14);
     // ---- restore the all-zero M and the empty tags for the next plane ----
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if ((wrote >> q) & 1) M[hs[q] * MS + i] = 0.f;
         if ((mine >> q) & 1) tags[hs[q]] = -1;
     }
+    TT_PHASE(15);
     // ---- references that lost their slot (tile footprint wider than the 8x8 window: sparse rays) go straight to
     // global memory, one half-wave per reference (lanes <-> channels: a coalesced 128-byte atomic each) ----
     if (__any(lost != 0) && !no_global) {
@@ -192,10 +245,12 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
                 const float v = Qs[sidx2 * 33 + i];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (c4[q] != 0.f) atomicAdd(grad + (size_t)o4[q] * TT_C + i, v * c4[q]);
+                    if (c4[q] != 0.f) atomicAdd(TT_TEXEL_ADDR(o4[q]), v * c4[q]);
             }
         }
     }
+#undef TT_TEXEL_ADDR
+    TT_PHASE(16);
 }
 
 struct MlpGradPtrs {
@@ -369,8 +424,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4)
                             aoff[q4] = (int)(pofs / TT_C) + (int)(pl * HW) + cs[pl].off[q4];
-                        scatter_plane<0, 16>(grad_out, Qs, q, coefs[pl], aoff, cs[pl].hs, Xs, tags, Qs + 32 * 33, i,
-                                             hi, cfg.flags);
+                        scatter_plane(grad_out, Qs, coefs[pl], aoff, cs[pl].hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags);
                     }
                 }
             }
@@ -403,18 +457,20 @@ struct BwdTexParams {
     int n_copies;
     float* grad_packed;
     MlpGradPtrs grads;
+    unsigned long long* phase_cycles;  // tuning build only (TT_PHASE), else null
 };
 
 #define TEX_W_FLOATS (LDS_W_FLOATS - OFF_V1)
 #define TV1 0
 #define TV2 (OFF_V2 - OFF_V1)
 #define TV3 (OFF_V3 - OFF_V1)
-#define TEX_SCRATCH_FLOATS ((64 + 96) * XS)
-// V1 and V1^T as split-fp16 images (tt_mfma16.h): k1 = V1 e and the per-plane ebar = V1_p^T k1bar run on the fp16
-// pipe.  V2 is used both ways too but stays ONE fp32 image with fp32 MFMAs: a second V2 image does not fit (the
-// kernel uses 163 072 of the CU's 163 840 LDS bytes) and its 160 accumulator registers leave little room anyway.
+// V1, V2 and their transposes as split-fp16 images (tt_mfma16.h): every mat-vec product of the kernel runs on the fp16
+// pipe.  To make room for the V2^T image the per-wave scratch is 128 rows (was 160): the parked e (96 rows) shares it
+// with a 32-row window through which k2 (for dV3) and k1bar (for dV1) are transposed in two halves.
 #define TV1T TEX_W_FLOATS
-#define TEX_W16_FLOATS (TV1T + IMG16_FLOATS(96, 64))
+#define TV2T (TV1T + IMG16_FLOATS(96, 64))
+#define TEX_W16_FLOATS (TV2T + IMG16_FLOATS(64, 64))
+#define TEX_SCRATCH_FLOATS (128 * XS)
 
 template <bool EXACT>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
@@ -422,16 +478,18 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     {
         MlpPtrs w = p.w;
         stage_weights<EXACT, 64, 96>(Lt + TV1, w.v1);
-        lds_load_matrix(Lt + TV2, w.v2, 64, 64, V2S);
+        stage_weights<EXACT, 64, 64>(Lt + TV2, w.v2);
         lds_load_matrix(Lt + TV3, w.v3, 3, 64, 64);
         stage_weights_t<EXACT, 64, 96>(Lt + TV1T, w.v1);
+        stage_weights_t<EXACT, 64, 64>(Lt + TV2T, w.v2);
     }
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5, wave_in_blk = threadIdx.x >> 6;
+    // per-wave scratch: rows 0..31 = Xs (transposition window / first half of bigger operands), rows 32..127 = Ys
     float* Xs = Lt + TEX_W16_FLOATS + wave_in_blk * (TEX_SCRATCH_FLOATS + 64);
-    float* Ys = Xs + 64 * XS;  // 96 rows
-    int* tags = reinterpret_cast<int*>(Ys + 96 * XS);
+    float* Ys = Xs + 32 * XS;  // 96 rows: the parked e
+    int* tags = reinterpret_cast<int*>(Xs + 128 * XS);
     // cbar of the tile, [3][32]: in the 4 pad columns of Xs rows 0..23 (row r holds floats 4r..4r+3 of the 96) --
     // stage_rows / the scatter matrix only touch columns 0..31 of a row
     float* Cb = Xs + 32;
@@ -450,7 +508,11 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     f32x16 accV1a[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};  // dV1[:, 0:64]
     f32x16 accV1b[2][1] = {{ZERO16}, {ZERO16}};                  // dV1[:, 64:96]
     f32x16 accV2[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};
-    float accV3[3] = {0.f, 0.f, 0.f};
+    float accV3[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // [half of the 64 indices][output]; this lane: 16 samples
+#ifdef TT_TUNING
+    unsigned long long ph_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph_t = __builtin_amdgcn_s_memtime();
+#endif
 
 #pragma nounroll
     for (;;) {
@@ -476,17 +538,26 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         const bool valid = ray_ok && si < s_end;
         const long long sidx = ray * S + (si < S ? si : S - 1);
         // ---- upstream: cbar_o = shrink * w_i * g_rgb[ray,o] * 1.002 * s(1-s) + g_features ----
-        float cb[3];
+        // (weights first: a tile whose rays are all dead -- w_i = 0 behind the surface, half of the tile steps of the
+        // bench scene -- is rejected after ONE load per lane, before the features are read and the logistic evaluated)
+        float cb[3] = {0.f, 0.f, 0.f};
         {
             const float wgt = (valid && p.weights) ? p.weights[sidx] : 0.f;  // null: no march above (points)
+            if (__any(wgt != 0.f)) {
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                const float s = p.weights ? sigmoidf_(p.features[sidx * 3 + o]) : 0.f;
-                float v = shrink * wgt * grgb[o] * 1.002f * s * (1.f - s);
-                if (p.g_features) v += p.g_features[sidx * 3 + o];
-                cb[o] = valid ? v : 0.f;
+                for (int o = 0; o < 3; ++o) {
+                    const float s = sigmoid_(p.features[sidx * 3 + o]);
+                    cb[o] = shrink * wgt * grgb[o] * 1.002f * s * (1.f - s);
+                }
             }
+            if (p.g_features) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) cb[o] += p.g_features[sidx * 3 + o];
+            }
+#pragma unroll
+            for (int o = 0; o < 3; ++o) cb[o] = valid ? cb[o] : 0.f;
         }
+        TT_PHASE(0);
         if (!__any(cb[0] != 0.f || cb[1] != 0.f || cb[2] != 0.f)) continue;  // exact: nothing flows back
         const float ts = p.rays_d ? p.t_starts[sidx] : 0.f, te = p.rays_d ? p.t_ends[sidx] : 0.f;
         float tm, px, py, pz;
@@ -494,34 +565,52 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius), Z = scale_coord(pz, cfg.radius);
         float e[48];
         const bool any = __any(gather_tex(p.packed + pofs, H, W, X, Y, Z, valid, hi, e, cfg.flags));
+        TT_PHASE(1);
         if (!any) continue;  // exact: e == 0 => k1 = k2 = 0 and every mask is false
         // e is needed again only as the Y operand of the dV1 outer product: park it in LDS now ([idx][sample]
         // layout, 96 rows) so its 48 registers are free during the MLP chain.
-        const bool do_wgrad = !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
+        // (`region`: always true -- tt_validate_cfg rejects negative flags -- but opaque to the compiler.  The two
+        // conditional regions below split this ~9000-instruction loop body into separate scheduling / allocation
+        // regions: 97 -> 45 spilled registers, 5.46 -> 4.84 ms.  __builtin_amdgcn_sched_barrier does not have that
+        // effect; found by noticing that the -DTT_TUNING build, whose ablation branches are live, was FASTER.)
+        const bool region = cfg.flags >= 0;
+        const bool do_wgrad = region && !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
         if (do_wgrad) stage_rows<96>(Ys, e, i, hi);
+        TT_PHASE(2);
         float k1[32], k2[32];
         mvx<EXACT, 64, 96>(Lt + TV1, e, k1, i, hi);
 #pragma unroll
         for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
-        mv_fwd<64, 64>(Lt + TV2, k1, k2, i, hi);
+        TT_PHASE(3);
+        mvx<EXACT, 64, 64>(Lt + TV2, k1, k2, i, hi);
 #pragma unroll
         for (int r = 0; r < 32; ++r) k2[r] = fmaxf(k2[r], 0.f);
-        // ---- dV3[o][idx] += sum_s cbar_o[s] k2[idx][s]  (lane <-> idx through the transposition scratch) ----
-        stage_rows<64>(Xs, k2, i, hi);
+        TT_PHASE(4);
+        // ---- dV3[o][idx] += sum_s cbar_o[s] k2[idx][s]: k2 goes through the 32-row window in two halves (registers
+        // 0..15 hold indices 0..31, registers 16..31 indices 32..63); lane (i, hi) sums samples 16 hi .. 16 hi + 15 of
+        // row i against cbar ----
         if (hi == 0) {
             CB_AT(0 * 32 + i) = cb[0];
             CB_AT(1 * 32 + i) = cb[1];
             CB_AT(2 * 32 + i) = cb[2];
         }
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            f32x4 kk = *reinterpret_cast<const f32x4*>(Xs + lane * XS + 4 * g);
+        for (int h2 = 0; h2 < 2; ++h2) {
+            if (h2 == 0)
+                stage_rows_sub<32, 0, 32>(Xs, k2, i, hi);
+            else
+                stage_rows_sub<32, 16, 32>(Xs, k2, i, hi);
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                f32x4 cc = *reinterpret_cast<const f32x4*>(&CB_AT(o * 32 + 4 * g));
-                accV3[o] += (kk[0] * cc[0] + kk[1] * cc[1]) + (kk[2] * cc[2] + kk[3] * cc[3]);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 kk = *reinterpret_cast<const f32x4*>(Xs + i * XS + 16 * hi + 4 * g);
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const f32x4 cc = *reinterpret_cast<const f32x4*>(&CB_AT(o * 32 + 16 * hi + 4 * g));
+                    accV3[h2][o] += (kk[0] * cc[0] + kk[1] * cc[1]) + (kk[2] * cc[2] + kk[3] * cc[3]);
+                }
             }
         }
+        TT_PHASE(5);
         // ---- k2bar = n2 . (V3^T cbar) ----
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -536,22 +625,37 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         }
         // ---- k1bar = n1 . (V2^T k2bar) ----
         float kb1[32];
-        mv_bwd<64, 64>(Lt + TV2, k2, kb1, i, hi);
+        mvtx<EXACT, 64, 64>(Lt + TV2T, Lt + TV2, k2, kb1, i, hi);
 #pragma unroll
         for (int r = 0; r < 32; ++r) kb1[r] = k1[r] > 0.f ? kb1[r] : 0.f;
+        TT_PHASE(6);
         if (do_wgrad) {
-            // ---- dV1 += k1bar e^T  (e parked in Ys rows 0..95) ----
-            stage_rows<64>(Xs, kb1, i, hi);
-            wgrad<64, 64>(accV1a, Xs, Ys, i, hi);
-            wgrad<64, 32>(accV1b, Xs, Ys + 64 * XS, i, hi);
-            // ---- dV2 += k2bar k1^T ----
+            // ---- dV1 += k1bar e^T  (e parked in Ys rows 0..95; k1bar through the 32-row window, half by half) ----
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                if (h2 == 0)
+                    stage_rows_sub<32, 0, 32>(Xs, kb1, i, hi);
+                else
+                    stage_rows_sub<32, 16, 32>(Xs, kb1, i, hi);
+                wgrad_row<64>(accV1a[h2], Xs, Ys, i, hi);
+                wgrad_row<32>(accV1b[h2], Xs, Ys + 64 * XS, i, hi);
+            }
+            TT_PHASE(7);
+            // ---- dV2 += k2bar k1^T  (e is dead: k2bar in rows 0..63, k1 in rows 64..127) ----
             stage_rows<64>(Xs, k2, i, hi);
-            stage_rows<64>(Ys, k1, i, hi);
-            wgrad<64, 64>(accV2, Xs, Ys, i, hi);
+            stage_rows<64>(Xs + 64 * XS, k1, i, hi);
+            wgrad<64, 64>(accV2, Xs, Xs + 64 * XS, i, hi);
+            TT_PHASE(8);
         }
         // ---- ebar = V1^T k1bar (one plane at a time) ; scatter texel(3+p, c)[ch] += w_c * ebar[32p + ch] ----
-        if (!TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
-            scatter_clear(Xs, lane);  // M = 0 (Xs held wgrad staging)
+        if (region && !TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
+            float* M = Xs;              // rows 0..63: the slot x sample coefficient matrix
+            float* Es = Xs + 64 * XS;   // rows 64..: ebar staged as [sample][32], stride 33, then the fallback lists
+            scatter_clear(M, lane);
+            // ebar = V1^T k1bar for the three planes in ONE product (96 rows: k1bar is split into fp16 terms once)
+            float eb[48];
+            mvtx<EXACT, 96, 64, V1S>(Lt + TV1T, Lt + TV1, kb1, eb, i, hi);
+            TT_PHASE(9);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 Corners c;
@@ -560,16 +664,23 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4)  // absolute texel index, prompt included
                     aoff[q4] = (int)(pofs / TT_C) + (int)((3 + pl) * HW) + c.off[q4];
-                float eb[16];  // ebar of this plane = (V1[:, 32pl : 32pl+32])^T k1bar
-                mvtx<EXACT, 32, 64, V1S>(Lt + TV1T + (size_t)32 * pl * (64 + 4), Lt + TV1 + 32 * pl, kb1, eb, i, hi);
-                float* Es = Ys;  // ebar staged as [sample][32], stride 33
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[r];
-                scatter_plane<0, 16>(grad_out, Es, eb, c.w, aoff, c.hs, Xs, tags, Es + 32 * 33, i, hi, cfg.flags);
+                for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[16 * pl + r];
+#ifdef TT_TUNING
+                scatter_plane(grad_out, Es, c.w, aoff, c.hs, M, tags, Es + 32 * 33, i, hi, cfg.flags, ph_acc, &ph_t);
+#else
+                scatter_plane(grad_out, Es, c.w, aoff, c.hs, M, tags, Es + 32 * 33, i, hi, cfg.flags);
+#endif
+                TT_PHASE(10);
             }
         }
       }
     }
+#ifdef TT_TUNING
+    TT_PHASE(11);
+    if (p.phase_cycles && lane == 0)
+        for (int k = 0; k < 20; ++k) atomicAdd(p.phase_cycles + k, ph_acc[k]);
+#endif
     // dV1 is (64, 96) row-major: columns 0..63 from accV1a, 64..95 from accV1b
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -582,7 +693,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         }
     flush_wgrad<64, 64>(accV2, p.grads.v2, i, hi);
 #pragma unroll
-    for (int o = 0; o < 3; ++o) atomicAdd(p.grads.v3 + o * 64 + lane, accV3[o]);
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) atomicAdd(p.grads.v3 + o * 64 + 32 * h2 + i, accV3[h2][o]);
 }
 
 // =====================================================================================================
@@ -618,6 +731,11 @@ static int debug_flags() {
 #endif
 }
 
+// the scatter addresses texels with 32-bit byte offsets from the (copy of the) gradient buffer
+static bool grad_buffer_too_large(const tt_render_cfg* cfg) {
+    return (long long)cfg->n_prompts * 6 * cfg->plane_h * cfg->plane_w * TT_C * 4 >= (1LL << 32);
+}
+
 // one 4-wave workgroup per CU (register- and LDS-limited), grid a multiple of 8 (XCD chunking)
 static long long persistent_blocks(long long n_items, int cus) {
     long long blocks = cus;
@@ -632,7 +750,27 @@ static void launch_bwd_geo(const BwdGeoParams& p, long long blocks, hipStream_t 
     else
         hipLaunchKernelGGL(k_decode_bwd_geo<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
-static void launch_bwd_tex(const BwdTexParams& p, long long blocks, hipStream_t s) {
+#ifdef TT_TUNING
+static unsigned long long* g_phase_cycles = nullptr;
+// tuning build only: cycles per phase of k_decode_bwd_tex summed over waves since the last call (host copy), then reset
+extern "C" int tt_tuning_phase_cycles(unsigned long long* out20) {
+    if (!g_phase_cycles) {
+        if (hipMalloc((void**)&g_phase_cycles, 20 * sizeof(unsigned long long)) != hipSuccess) return -4;
+        if (hipMemset(g_phase_cycles, 0, 20 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (out20 && hipMemcpy(out20, g_phase_cycles, 20 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return -4;
+    return hipMemset(g_phase_cycles, 0, 20 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
+}
+#endif
+static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t s) {
+    BwdTexParams p = p0;
+#ifdef TT_TUNING
+    p.phase_cycles = g_phase_cycles;
+#else
+    p.phase_cycles = nullptr;
+#endif
     if (p.cfg.flags & TT_R_EXACT_F32)
         hipLaunchKernelGGL(k_decode_bwd_tex<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     else
@@ -660,6 +798,7 @@ extern "C" int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, c
         !sdf_grad || !features || !workspace || !grad_packed || !grads)
         return TT_ERR_BAD_ARG;
     if (!w->w1 || !w->w2 || !w->w3 || !grads->w1 || !grads->w2 || !grads->w3) return TT_ERR_BAD_ARG;
+    if (grad_buffer_too_large(cfg)) return TT_ERR_UNSUPPORTED;
     int cus = tt_num_cus();
     if (cus <= 0) return TT_ERR_DEVICE;
     hipStream_t s = (hipStream_t)stream;
@@ -700,6 +839,7 @@ extern "C" int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, c
         !grads)
         return TT_ERR_BAD_ARG;
     if (!w->v1 || !w->v2 || !w->v3 || !grads->v1 || !grads->v2 || !grads->v3) return TT_ERR_BAD_ARG;
+    if (grad_buffer_too_large(cfg)) return TT_ERR_UNSUPPORTED;
     int cus = tt_num_cus();
     if (cus <= 0) return TT_ERR_DEVICE;
     BwdTexParams p;
@@ -772,6 +912,7 @@ extern "C" int tt_points_bwd_geo(const float* packed, const tt_mlp_weights* w, c
     int st = points_cfg(&cfg, n_batch, n_points, n_prompts, views_per_prompt, plane_h, plane_w, radius,
                         sdf_bias_radius, 1, flags);
     if (st != TT_OK) return st;
+    if (grad_buffer_too_large(&cfg)) return TT_ERR_UNSUPPORTED;
     if (!packed || !w || !points || !workspace || !grad_packed || !grads || (!g_sdf && !g_sdf_grad))
         return TT_ERR_BAD_ARG;
     if (!w->w1 || !w->w2 || !w->w3 || !grads->w1 || !grads->w2 || !grads->w3) return TT_ERR_BAD_ARG;
@@ -813,6 +954,7 @@ extern "C" int tt_points_bwd_tex(const float* packed, const tt_mlp_weights* w, c
     int st = points_cfg(&cfg, n_batch, n_points, n_prompts, views_per_prompt, plane_h, plane_w, radius, 0.5f, 1,
                         flags);
     if (st != TT_OK) return st;
+    if (grad_buffer_too_large(&cfg)) return TT_ERR_UNSUPPORTED;
     if (!packed || !w || !points || !g_features || !grad_packed || !grads) return TT_ERR_BAD_ARG;
     if (!w->v1 || !w->v2 || !w->v3 || !grads->v1 || !grads->v2 || !grads->v3) return TT_ERR_BAD_ARG;
     if (plane_base != 0 && plane_base != 3) return TT_ERR_BAD_ARG;

@@ -638,6 +638,7 @@ int tt_validate_cfg(const tt_render_cfg* cfg) {
     if (cfg->n_rays != (int64_t)cfg->n_prompts * cfg->views_per_prompt * cfg->rays_per_view) return TT_ERR_BAD_ARG;
     if (cfg->plane_h <= 0 || cfg->plane_h != cfg->plane_w) return TT_ERR_UNSUPPORTED;
     if (!(cfg->radius > 0.f) || !(cfg->inv_std > 0.f)) return TT_ERR_BAD_ARG;
+    if (cfg->flags < 0) return TT_ERR_BAD_ARG;  // (the kernels use `flags >= 0` as an always-true opaque condition)
     return TT_OK;
 }
 
