@@ -29,7 +29,7 @@ def step():
 
 lib = _lib.load()
 lib.tt_tuning_phase_cycles.argtypes = [ctypes.c_void_p]
-buf = (ctypes.c_uint64 * 20)()
+buf = (ctypes.c_uint64 * 40)()
 lib.tt_tuning_phase_cycles(buf)  # allocate + reset
 step()
 lib.tt_tuning_phase_cycles(buf)  # warm-up discarded
@@ -43,9 +43,15 @@ names = ["upstream cbar + skip test", "gather e (12 corners)", "park e in LDS", 
          "  scatter: slot claims (LDS CAS) + M fill", "  scatter: combine GEMM M Q (fp32 MFMA)",
          "  scatter: flush (predicated 128-byte atomics)", "  scatter: restore M / tags", "  scatter: lost-reference fallback",
          "", "", ""]
-tot = sum(buf)
-for k, nm in enumerate(names):
-    if not nm:
-        continue
-    print(f"{nm:38s} {buf[k] / n / 1024 / 1e3:9.1f} k cycles per wave-launch   {100.0 * buf[k] / tot:5.1f} %")
-print(f"total {tot / n / 1024 / 1e6:.2f} M cycles per wave (100 MHz s_memtime ticks?)")
+geo_names = ["upstream (d sdf, d sdf_grad) + skip test", "gather f, u (12 corners)", "", "sdf net recompute + reverse chain (5 products)",
+             "a1bar = W1 qbar, v", "a2bar = W2 b1bar, dw3 (transpose + VALU)", "", "dW1 outer products",
+             "dW2 outer products", "scatter: q staging + corner set-up", "scatter epilogue", "tail",
+             "  scatter: slot claims (LDS CAS) + M fill", "  scatter: combine GEMM M Q (fp32 MFMA)",
+             "  scatter: flush (predicated 128-byte atomics)", "  scatter: restore M / tags",
+             "  scatter: lost-reference fallback", "", "", ""]
+for title, ofs, nms in (("k_decode_bwd_tex", 0, names), ("k_decode_bwd_geo", 20, geo_names)):
+    tot = sum(buf[ofs:ofs + 20])
+    print(f"== {title}: {tot / n / 1024 / 1e6:.2f} M shader cycles per wave ==")
+    for k, nm in enumerate(nms):
+        if nm:
+            print(f"{nm:48s} {buf[ofs + k] / n / 1024 / 1e3:9.1f} k cycles per wave   {100.0 * buf[ofs + k] / tot:5.1f} %")

@@ -280,6 +280,7 @@ struct BwdGeoParams {
     int n_copies;     // privatised copies of grad_packed
     float* grad_packed;
     MlpGradPtrs grads;
+    unsigned long long* phase_cycles;  // tuning build only (TT_PHASE), else null
 };
 
 #define GEO_SCRATCH_FLOATS (2 * 64 * XS)
@@ -321,6 +322,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     f32x16 accW1[2][1] = {{ZERO16}, {ZERO16}};
     f32x16 accW2[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};
     float accw3 = 0.f;
+#ifdef TT_TUNING
+    unsigned long long ph_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph_t = __builtin_amdgcn_s_memtime();
+#endif
 
 #pragma nounroll
     for (;;) {
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             f32x4 up = *reinterpret_cast<const f32x4*>(p.ws + sidx * 4);
             float sbar = rvalid ? up[0] : 0.f, gbx = rvalid ? up[1] : 0.f, gby = rvalid ? up[2] : 0.f,
                   gbz = rvalid ? up[3] : 0.f;
+            TT_PHASE(0);
             if (!__any(sbar != 0.f || gbx != 0.f || gby != 0.f || gbz != 0.f)) continue;  // exact
             const float ts = p.rays_d ? p.t_starts[sidx] : 0.f, te = p.rays_d ? p.t_ends[sidx] : 0.f;
             float tm, px, py, pz;
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             float coefs[3][4];   // per (plane, corner): w sbar + dw/dx . gbar -- gather AND scatter coefficient
             const bool any = __any(gather_geo_bwd(pbase, H, W, X, Y, Z, rvalid, sbar, gbx, gby, gbz, ju, jv, hi, f, u,
                                                   cs, coefs, cfg.flags));
+            TT_PHASE(1);
             if (!any) continue;  // exact: no in-bounds texel => f = J = 0, every mask false
             float h1[32], h2[32], a2[32], a1[32], q[16];
             mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
@@ -378,6 +385,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
             mvtx<EXACT, 32, 64>(L + GOFF_W1T, L + OFF_W1, a1, q, i, hi);
+            TT_PHASE(3);
             // ---- network + plane gradients ----
             {
                 float qb[16];
@@ -390,6 +398,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                     stage_rows<32>(Ys, u, i, hi);
                     wgrad<64, 32>(accW1, Xs, Ys, i, hi);
                 }
+                TT_PHASE(7);
                 // a1bar = W1 qbar ; b1bar = m1 . a1bar ; v = sbar h1 + b1bar
                 float t1[32];
                 mvx<EXACT, 64, 32>(L + OFF_W1, qb, t1, i, hi);
@@ -398,12 +407,14 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 float v[32];
 #pragma unroll
                 for (int r = 0; r < 32; ++r) v[r] = fmaf(sbar, h1[r], t1[r]);
+                TT_PHASE(4);
                 // dW2 += a2 v^T
                 if (do_wgrad) {
                     stage_rows<64>(Xs, a2, i, hi);
                     stage_rows<64>(Ys, v, i, hi);
                     wgrad<64, 64>(accW2, Xs, Ys, i, hi);
                 }
+                TT_PHASE(8);
                 // a2bar = W2 b1bar ; dw3 += sbar h2 + m2 . a2bar
                 float t2[32];
                 mvx<EXACT, 64, 64>(L + OFF_W2, t1, t2, i, hi);
@@ -411,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 for (int r = 0; r < 32; ++r) t2[r] = fmaf(sbar, h2[r], h2[r] > 0.f ? t2[r] : 0.f);
                 stage_rows<64>(Xs, t2, i, hi);
                 accw3 += rowsum32(Xs, lane);
+                TT_PHASE(5);
                 // ---- scatter d/d geometry planes: texel(p,c)[ch] += q[ch] * coef(p,c) ----
                 if (!TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
                     scatter_clear(Xs, lane);  // M = 0 (Xs held wgrad staging)
@@ -424,12 +436,24 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4)
                             aoff[q4] = (int)(pofs / TT_C) + (int)(pl * HW) + cs[pl].off[q4];
+                        TT_PHASE(9);
+#ifdef TT_TUNING
+                        scatter_plane(grad_out, Qs, coefs[pl], aoff, cs[pl].hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags,
+                                      ph_acc, &ph_t);
+#else
                         scatter_plane(grad_out, Qs, coefs[pl], aoff, cs[pl].hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags);
+#endif
                     }
+                    TT_PHASE(10);
                 }
             }
         }
     }
+#ifdef TT_TUNING
+    TT_PHASE(11);
+    if (p.phase_cycles && lane == 0)
+        for (int k = 0; k < 20; ++k) atomicAdd(p.phase_cycles + 20 + k, ph_acc[k]);
+#endif
     // ---- flush the persistent weight-gradient accumulators ----
     flush_wgrad<64, 32>(accW1, p.grads.w1, i, hi);
     flush_wgrad<64, 64>(accW2, p.grads.w2, i, hi);
@@ -744,26 +768,32 @@ static long long persistent_blocks(long long n_items, int cus) {
     return (blocks + 7) / 8 * 8;
 }
 
-static void launch_bwd_geo(const BwdGeoParams& p, long long blocks, hipStream_t s) {
+#ifdef TT_TUNING
+static unsigned long long* g_phase_cycles = nullptr;
+// tuning build only: cycles per phase of k_decode_bwd_tex summed over waves since the last call (host copy), then reset
+extern "C" int tt_tuning_phase_cycles(unsigned long long* out40) {
+    if (!g_phase_cycles) {
+        if (hipMalloc((void**)&g_phase_cycles, 40 * sizeof(unsigned long long)) != hipSuccess) return -4;
+        if (hipMemset(g_phase_cycles, 0, 40 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (out40 && hipMemcpy(out40, g_phase_cycles, 40 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return -4;
+    return hipMemset(g_phase_cycles, 0, 40 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
+}
+#endif
+static void launch_bwd_geo(const BwdGeoParams& p0, long long blocks, hipStream_t s) {
+    BwdGeoParams p = p0;
+#ifdef TT_TUNING
+    p.phase_cycles = g_phase_cycles;
+#else
+    p.phase_cycles = nullptr;
+#endif
     if (p.cfg.flags & TT_R_EXACT_F32)
         hipLaunchKernelGGL(k_decode_bwd_geo<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL(k_decode_bwd_geo<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
-#ifdef TT_TUNING
-static unsigned long long* g_phase_cycles = nullptr;
-// tuning build only: cycles per phase of k_decode_bwd_tex summed over waves since the last call (host copy), then reset
-extern "C" int tt_tuning_phase_cycles(unsigned long long* out20) {
-    if (!g_phase_cycles) {
-        if (hipMalloc((void**)&g_phase_cycles, 20 * sizeof(unsigned long long)) != hipSuccess) return -4;
-        if (hipMemset(g_phase_cycles, 0, 20 * sizeof(unsigned long long)) != hipSuccess) return -4;
-    }
-    if (hipDeviceSynchronize() != hipSuccess) return -4;
-    if (out20 && hipMemcpy(out20, g_phase_cycles, 20 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
-        return -4;
-    return hipMemset(g_phase_cycles, 0, 20 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
-}
-#endif
 static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t s) {
     BwdTexParams p = p0;
 #ifdef TT_TUNING
