@@ -5,7 +5,7 @@
  * raw DEVICE pointers (fp32 unless noted), explicit sizes, a config struct, a hipStream_t
  * passed as void*.  The caller (PyTorch-ROCm host code, or any FFI) allocates every output
  * and workspace; the library itself keeps one 266 KB device scratch per GPU (work-queue counters of the per-sample
- * kernels: one 64-byte slot per stream, zeroed on the stream in front of every launch, and a never-reused slot per
+ * kernels: one 64-byte slot per stream, zeroed on the stream (by a one-wave kernel) in front of every launch, and a never-reused slot per
  * launch recorded under stream capture, so a launch can be captured in a hipGraph; allocated at the first launch,
  * which therefore must not be inside a capture); no environment variable is read; re-entrant; safe from one
  * host thread per device.  Return 0 on success, a negative tt_status on error (no C++
@@ -47,6 +47,8 @@
  *   tt_points_bwd_geo /     the autograd backward of tt_query_points / tt_query_field w.r.t. planes and MLP weights
  *   tt_points_bwd_tex       (training-time callers: generative_space_mesh_rasterize_renderer.py:428-452 field
  *                           query, :321-376 per-pixel geometry decode); same kernels as tt_render_bwd_*.
+ *   tt_composite_fwd/_bwd   the renderer's per-ray composite: comp_rgb, disparity, comp_normal, camera-space normal
+ *                           maps (generative_space_sdf_volume_renderer.py:433-530)
  *   tt_patch_composite_*    PatchRenderer.forward's upsample + paste per output key (patch_renderer.py:74-88)
  *   tt_hashgrid_fwd / _bwd  tiny-cuda-nn's `HashGrid` encoding as used by the background
  *                           (multi_prompt_neural_environment_hashgrid_map_background.py:25-34,54,104-105 via
@@ -298,6 +300,26 @@ int tt_patch_composite_fwd(const float* low, const float* patch, float* out, int
                            int32_t W, int32_t C, int32_t PS, int32_t py, int32_t px, void* stream);
 int tt_patch_composite_bwd(const float* g_out, float* g_low, float* g_patch, int32_t B, int32_t h, int32_t w, int32_t H,
                            int32_t W, int32_t C, int32_t PS, int32_t py, int32_t px, void* stream);
+
+/* The renderer's per-ray composite (generative_space_sdf_volume_renderer.py:433-530) as one kernel each way:
+ *   comp_rgb = rgb_fg + bg (1 - opacity)                                   bg: (3) with bg_stride 0, or (n,3) with 3
+ *   disparity = clamp((far - (depth opacity + (1 - opacity) far)) / (far - near), 0, 1), far/near = d_cam +- sqrt(3)
+ *   comp_normal = normalize(normal_acc)
+ *   mode 1 ("camera"): n_cam = comp_normal @ inverse(c2w)[:3,:3]^T @ diag(-1,1,1);
+ *                      normal_cam_vis = (n_cam+1)/2 opacity + (1-opacity) (0.5,0.5,1), _white with (1,1,1)
+ *   mode 2 ("front") : the camera of view (v / view_group) * view_group, no flip, _white only;  mode 0 ("world"): neither.
+ * _bwd: gradients w.r.t. opacity, depth, rgb_fg, normal_acc and, if g_bg is given, the PER-RAY background colour (n,3)
+ * (a constant colour's gradient is its sum over rays), all overwritten, from the upstream gradients (null = 0). */
+int tt_composite_fwd(const float* opacity, const float* depth, const float* rgb_fg, const float* normal_acc,
+                     const float* bg, int32_t bg_stride, const float* camera_distances, const float* c2w, int64_t n_rays,
+                     int32_t rays_per_view, int32_t mode, int32_t view_group, float* comp_rgb, float* disparity,
+                     float* comp_normal, float* normal_cam_vis, float* normal_cam_vis_white, void* stream);
+int tt_composite_bwd(const float* opacity, const float* depth, const float* rgb_fg, const float* normal_acc,
+                     const float* bg, int32_t bg_stride, const float* camera_distances, const float* c2w, int64_t n_rays,
+                     int32_t rays_per_view, int32_t mode, int32_t view_group, const float* g_comp_rgb,
+                     const float* g_disparity, const float* g_comp_normal, const float* g_normal_cam_vis,
+                     const float* g_normal_cam_vis_white, float* g_opacity, float* g_depth, float* g_rgb_fg,
+                     float* g_normal_acc, float* g_bg, void* stream);
 
 /* Operator-level drop-in for the reference's pybind op `gridsample_grad2.grad2_2d`
  * (gridsample_cuda.cpp:26-37): backward of aten::grid_sampler_2d_backward, bilinear.  Contiguous fp32:

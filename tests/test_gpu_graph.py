@@ -1,5 +1,5 @@
 """The differentiable render step can be captured in a hipGraph (torch.cuda.graph) and replayed: the per-XCD work-queue
-counters of the decode kernels are zeroed by a memset node in front of each kernel node (a slot of their own per
+counters of the decode kernels are zeroed by a one-wave kernel node in front of each kernel node (a slot of their own per
 captured launch), and the composite uses no host-synchronising op.  Replays must reproduce the eager result every
 time -- a dirty counter would make a replay pop no work and leave stale outputs.  Also: a dirty counter slot (what a
 faulted / killed kernel leaves behind) must not affect the next launch, and launches on different streams must not

@@ -95,16 +95,6 @@ def test_sampler_has_no_cpu_path():
         sampler.importance_sampling(lambda a, b: a, 5, 32, 16, 0.1, 4.0, 100.0, 0.05, device="cpu")
 
 
-def test_world_to_camera_rotation_is_the_block_of_the_full_inverse():
-    """functional._rot_world_to_cam replaces torch.inverse(c2w)[:, :3, :3] (renderer :478-479; host-synchronising, not
-    graph-capturable) by the closed-form inverse of the 3x3 block -- identical for affine camera matrices."""
-    from triplaneturbo_amd import functional
-    _, _, c2w, _ = O.make_cameras(6, 4, 4, azimuth_start_deg=33.0)
-    c2w = c2w.clone()
-    c2w[:, :3, :3] = c2w[:, :3, :3] @ torch.diag(torch.tensor([1.0, 2.0, 0.5]))  # not orthonormal on purpose
-    torch.testing.assert_close(functional._rot_world_to_cam(c2w), torch.inverse(c2w)[:, :3, :3], rtol=1e-5, atol=1e-6)
-
-
 def test_reference_training_yaml_loads_into_the_plugins():
     """Drop-in check at the config level: the reference's own training config (configs/TriplaneTurbo_v1.yaml) must
     instantiate our geometry / material / background / patch renderer with every key it sets (unknown keys raise).

@@ -30,12 +30,12 @@ int tt_num_cus() {
 namespace {
 // Work-queue counter slots: 64 B each (8 per-XCD heads + padding: one cache line).
 //   * eager launches: ONE slot per (device, stream).  Launches on a stream are ordered, and every launch first
-//     enqueues a 64-byte hipMemsetAsync of its slot on that stream, so a slot is clean whatever happened to the
+//     enqueues a one-wave kernel that zeroes its slot on that stream, so a slot is clean whatever happened to the
 //     previous kernel that used it (fault, kill) and two launches that may run concurrently (different streams)
 //     never share counters.
 //   * launches recorded during a stream capture: a slot of their own from a second pool, never handed out again (a
-//     graph may be replayed on any stream, concurrently with eager launches on the capture stream); the memset is
-//     captured as a memset node in front of the kernel node.
+//     graph may be replayed on any stream, concurrently with eager launches on the capture stream); the zeroing
+//     kernel is captured as a node in front of the kernel node.
 constexpr int kMaxDevices = 64, kStreamSlots = 64, kGraphSlots = 4096, kSlotInts = 16;
 struct DeviceScratch {
     int* base = nullptr;                 // (kStreamSlots + kGraphSlots) * kSlotInts ints
@@ -46,6 +46,8 @@ struct DeviceScratch {
 DeviceScratch g_scratch[kMaxDevices];
 std::mutex g_scratch_mu;
 }  // namespace
+
+__global__ void k_zero_slot(int* slot) { slot[threadIdx.x] = 0; }
 
 int* tt_queue_counters(hipStream_t stream) {
     int dev = 0;
@@ -83,7 +85,11 @@ int* tt_queue_counters(hipStream_t stream) {
             slot = d.base + (size_t)k * kSlotInts;
         }
     }
-    if (hipMemsetAsync(slot, 0, kSlotInts * sizeof(int), stream) != hipSuccess) return nullptr;
+    // zeroed by a one-wave KERNEL, not hipMemsetAsync: as a graph node the 64-byte memset was not reliably re-executed
+    // in front of its kernel on replays >= 2 once few other nodes separated the launches (ROCm 7.2; tests/test_gpu_graph.py
+    // caught it: a replay popped no work), a kernel node is
+    hipLaunchKernelGGL(k_zero_slot, dim3(1), dim3(kSlotInts), 0, stream, slot);
+    if (hipGetLastError() != hipSuccess) return nullptr;
     return slot;
 }
 

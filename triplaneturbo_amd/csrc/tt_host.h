@@ -16,7 +16,7 @@ struct TileGeom;
 long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g, int default_order);
 
 // Work-queue counters for one kernel launch: 8 int32 heads (one per XCD) in a library-owned device scratch, zeroed on
-// `stream` by a hipMemsetAsync enqueued here (so the caller must launch the kernel on the same stream, next).  One
+// `stream` by a one-wave kernel enqueued here (so the caller must launch the kernel on the same stream, next).  One
 // slot per (device, stream) for eager launches, a fresh never-reused slot per launch recorded under stream capture
 // (see tt_host.cpp).  Returns nullptr on a HIP error.  (The only state the library keeps: a 266 KB allocation per
 // device, never freed; its first use must not happen inside a stream capture.)

@@ -1,9 +1,8 @@
-"""Renderer-level composite on top of the fused op: everything GenerativeSpaceSDFVolumeRenderer._forward does
-with the per-ray accumulators (reference generative_space_sdf_volume_renderer.py:433-546).  These are a handful
-of (n_rays, .)-sized torch ops; the per-sample hot path lives in the HIP kernels."""
+"""Renderer-level orchestration on top of the fused ops: everything GenerativeSpaceSDFVolumeRenderer._forward does
+with the per-ray accumulators (reference generative_space_sdf_volume_renderer.py:433-546) -- the per-ray composite is
+one HIP kernel each way (tt_composite_fwd / _bwd), the per-sample extras of the training mode are lazy views."""
 from __future__ import annotations
 
-import math
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -12,17 +11,6 @@ import torch.nn.functional as F
 from . import ops
 
 Tensor = torch.Tensor
-
-
-def _rot_world_to_cam(c2w: Tensor) -> Tensor:
-    """inverse(c2w)[:, :3, :3] (renderer :478-479) for affine camera matrices (last row 0 0 0 1), as the closed-form
-    inverse of the 3x3 block: rows of the inverse = cross products of the columns / det.  torch.inverse synchronises
-    with the host (pivoting info) and cannot be captured in a hipGraph; this is a handful of element-wise kernels."""
-    m = c2w[:, :3, :3]
-    c0, c1, c2 = m[:, :, 0], m[:, :, 1], m[:, :, 2]
-    r0, r1, r2 = torch.cross(c1, c2, dim=-1), torch.cross(c2, c0, dim=-1), torch.cross(c0, c1, dim=-1)
-    det = (c0 * r0).sum(dim=-1, keepdim=True)
-    return torch.stack([r0, r1, r2], dim=1) / det[:, :, None]
 
 
 class LazyOutputs(dict):
@@ -116,13 +104,17 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
                                packed=packed)
     opacity, depth, comp_rgb_fg, z_variance = r["opacity"], r["depth"], r["rgb_fg"], r["z_variance"]
 
-    if bg_color.ndim == 1:
-        bg = bg_color[None, :].expand(n_rays, -1)
-    else:
-        bg = bg_color.reshape(n_rays, -1)  # renderer :436-437
-    comp_rgb = comp_rgb_fg + bg * (1.0 - opacity)  # :439
+    if normal_direction not in ("camera", "front", "world"):
+        raise ValueError(normal_direction)
+    bg = bg_color if bg_color.ndim == 1 else bg_color.reshape(n_rays, -1)  # renderer :436-437
     if comp_rgb_bg is None:
-        comp_rgb_bg = bg
+        comp_rgb_bg = bg[None, :].expand(n_rays, -1) if bg.ndim == 1 else bg
+    n_prompts = packed.shape[0] if packed is not None else space_cache.shape[0]
+    # one HIP kernel each way (tt_composite_fwd / _bwd)
+    comp = ops.composite(opacity, depth, comp_rgb_fg, r["normal_acc"], bg.contiguous(),
+                         camera_distances.reshape(-1).contiguous().float(), c2w.contiguous().float(), Hh * Ww,
+                         normal_direction, view_group=B // n_prompts)
+    comp_rgb, disparity, comp_normal, vis, vis_white = comp
     out = LazyOutputs({
         "comp_rgb": comp_rgb.view(B, Hh, Ww, -1),
         "comp_rgb_fg": comp_rgb_fg.view(B, Hh, Ww, -1),
@@ -130,39 +122,13 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
         "opacity": opacity.view(B, Hh, Ww, 1),
         "depth": depth.view(B, Hh, Ww, 1),
         "z_variance": z_variance.view(B, Hh, Ww, 1),
+        "disparity": disparity.view(B, Hh, Ww, 1),       # :452-462
+        "comp_normal": comp_normal.view(B, Hh, Ww, 3),   # :466-477
     })
-    # :452-462
-    cd = camera_distances.reshape(-1, 1, 1, 1)
-    far = cd + math.sqrt(3.0)
-    near = cd - math.sqrt(3.0)
-    disparity_tmp = out["depth"] * out["opacity"] + (1.0 - out["opacity"]) * far
-    out["disparity"] = torch.clamp((far - disparity_tmp) / (far - near), 0.0, 1.0).view(B, Hh, Ww, 1)
-
-    # :466-530
-    comp_normal = F.normalize(r["normal_acc"], dim=-1)
-    out["comp_normal"] = comp_normal.view(B, Hh, Ww, 3)
-    if normal_direction == "camera":
-        # (device-side constants only: no host scalars written into GPU tensors, so the step can be graph-captured)
-        bg_normal = torch.cat([torch.full_like(comp_normal[:, :2], 0.5), torch.ones_like(comp_normal[:, :1])], dim=-1)
-        bg_normal_white = torch.ones_like(comp_normal)
-        rot = _rot_world_to_cam(c2w)
-        comp_normal_cam = (comp_normal.view(B, -1, 3) @ rot.permute(0, 2, 1)).view(-1, 3)
-        comp_normal_cam = torch.cat([-comp_normal_cam[:, :1], comp_normal_cam[:, 1:]], dim=-1)  # @ diag(-1, 1, 1)
-        out["comp_normal_cam_vis"] = ((comp_normal_cam + 1.0) / 2.0 * opacity + (1 - opacity) * bg_normal).view(
-            B, Hh, Ww, 3)
-        out["comp_normal_cam_vis_white"] = (
-            (comp_normal_cam + 1.0) / 2.0 * opacity + (1 - opacity) * bg_normal_white).view(B, Hh, Ww, 3)
-    elif normal_direction == "front":
-        n_prompts = space_cache.shape[0]
-        nv = B // n_prompts
-        bg_normal_white = torch.ones_like(comp_normal)
-        c2w_front = c2w[0::nv].repeat_interleave(nv, dim=0)
-        rot = _rot_world_to_cam(c2w_front)
-        comp_normal_front = (comp_normal.view(B, -1, 3) @ rot.permute(0, 2, 1)).view(-1, 3)
-        out["comp_normal_cam_vis_white"] = (
-            (comp_normal_front + 1.0) / 2.0 * opacity + (1 - opacity) * bg_normal_white).view(B, Hh, Ww, 3)
-    elif normal_direction != "world":
-        raise ValueError(normal_direction)
+    if vis is not None:                                   # :478-530
+        out["comp_normal_cam_vis"] = vis.view(B, Hh, Ww, 3)
+    if vis_white is not None:
+        out["comp_normal_cam_vis_white"] = vis_white.view(B, Hh, Ww, 3)
 
     if training:  # :532-545 -- per-sample extras; kernel outputs are eager, derived tensors are lazy
         grad_mode = torch.is_grad_enabled()

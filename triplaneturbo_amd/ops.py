@@ -638,3 +638,70 @@ def patch_composite(low: Tensor, patch: Tensor, py: int, px: int, H: int, W: int
     """(B,h,w,C) low-resolution image upsampled bilinearly (align_corners=False) to (B,H,W,C) with `patch`
     (B,PS,PS,C) pasted at rows py.., columns px..; differentiable w.r.t. both (low: unless detach_low)."""
     return _PatchCompositeFn.apply(low, patch, int(py), int(px), int(H), int(W), bool(detach_low))
+
+
+_COMPOSITE_MODES = {"world": 0, "camera": 1, "front": 2}
+
+
+class _CompositeFn(torch.autograd.Function):
+    """tt_composite_fwd / _bwd: the renderer's per-ray composite (renderer :433-530) as one kernel each way.
+    Differentiable inputs: opacity, depth, rgb_fg, normal_acc and the background colour (a learned background,
+    background.py); the cameras are constants."""
+
+    @staticmethod
+    def forward(ctx, opacity, depth, rgb_fg, normal_acc, bg, cam_dist, c2w, rays_per_view, mode, view_group):
+        opacity, depth = _chk(opacity, "opacity"), _chk(depth, "depth")
+        rgb_fg, normal_acc = _chk(rgb_fg, "rgb_fg"), _chk(normal_acc, "normal_acc")
+        bg, cam_dist, c2w = _chk(bg, "bg_color"), _chk(cam_dist, "camera_distances"), _chk(c2w, "c2w")
+        n = opacity.numel()
+        bg_stride = 0 if bg.numel() == 3 else 3
+        if bg_stride and bg.numel() != 3 * n:
+            raise ValueError("bg_color must have 3 or 3 * n_rays elements")
+        f32 = dict(device=opacity.device, dtype=torch.float32)
+        comp_rgb, comp_normal = torch.empty((n, 3), **f32), torch.empty((n, 3), **f32)
+        disparity = torch.empty((n, 1), **f32)
+        vis = torch.empty((n, 3), **f32) if mode == 1 else None
+        vis_white = torch.empty((n, 3), **f32) if mode != 0 else None
+        st = _lib.load().tt_composite_fwd(_ptr(opacity), _ptr(depth), _ptr(rgb_fg), _ptr(normal_acc), _ptr(bg),
+                                          bg_stride, _ptr(cam_dist), _ptr(c2w), n, rays_per_view, mode, view_group,
+                                          _ptr(comp_rgb), _ptr(disparity), _ptr(comp_normal), _ptr(vis),
+                                          _ptr(vis_white), _stream())
+        _lib.check(st, "tt_composite_fwd")
+        ctx.save_for_backward(opacity, depth, rgb_fg, normal_acc, bg, cam_dist, c2w)
+        ctx.meta = (n, bg_stride, rays_per_view, mode, view_group)
+        ctx.set_materialize_grads(False)
+        dummy = comp_rgb.new_zeros(0)
+        outs = (comp_rgb, disparity, comp_normal, vis if vis is not None else dummy,
+                vis_white if vis_white is not None else dummy)
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rgb, g_disp, g_cn, g_vis, g_visw):
+        opacity, depth, rgb_fg, normal_acc, bg, cam_dist, c2w = ctx.saved_tensors
+        n, bg_stride, rays_per_view, mode, view_group = ctx.meta
+        c = lambda t: None if (t is None or t.numel() == 0) else t.contiguous()
+        g_rgb, g_disp, g_cn, g_vis, g_visw = c(g_rgb), c(g_disp), c(g_cn), c(g_vis), c(g_visw)
+        f32 = dict(device=opacity.device, dtype=torch.float32)
+        g_op, g_dep = torch.empty((n, 1), **f32), torch.empty((n, 1), **f32)
+        g_fg, g_na = torch.empty((n, 3), **f32), torch.empty((n, 3), **f32)
+        g_bg = torch.empty((n, 3), **f32) if ctx.needs_input_grad[4] else None
+        st = _lib.load().tt_composite_bwd(_ptr(opacity), _ptr(depth), _ptr(rgb_fg), _ptr(normal_acc), _ptr(bg),
+                                          bg_stride, _ptr(cam_dist), _ptr(c2w), n, rays_per_view, mode, view_group,
+                                          _ptr(g_rgb), _ptr(g_disp), _ptr(g_cn), _ptr(g_vis), _ptr(g_visw), _ptr(g_op),
+                                          _ptr(g_dep), _ptr(g_fg), _ptr(g_na), _ptr(g_bg), _stream())
+        _lib.check(st, "tt_composite_bwd")
+        if g_bg is not None:
+            g_bg = g_bg.sum(dim=0).view_as(bg) if bg_stride == 0 else g_bg.view_as(bg)
+        return g_op, g_dep, g_fg, g_na, g_bg, None, None, None, None, None
+
+
+def composite(opacity: Tensor, depth: Tensor, rgb_fg: Tensor, normal_acc: Tensor, bg_color: Tensor,
+              camera_distances: Tensor, c2w: Tensor, rays_per_view: int, normal_direction: str = "camera",
+              view_group: int = 1):
+    """Per-ray composite of the renderer (renderer :433-530): returns comp_rgb (n,3), disparity (n,1), comp_normal
+    (n,3), comp_normal_cam_vis (n,3) | None, comp_normal_cam_vis_white (n,3) | None."""
+    mode = _COMPOSITE_MODES[normal_direction]
+    rgb, disp, cn, vis, visw = _CompositeFn.apply(opacity, depth, rgb_fg, normal_acc, bg_color, camera_distances, c2w,
+                                                  int(rays_per_view), mode, int(view_group))
+    return rgb, disp, cn, (vis if mode == 1 else None), (visw if mode != 0 else None)
