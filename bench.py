@@ -60,7 +60,7 @@ def _tex_macs(exact):
     # dV1 (6144)
     if exact:
         return {"f16x3": 0, "f32": 4096 + 6144 + 4096 + 6144, "valu": 384}
-    return {"f16x3": 6144, "f32": 4096 + 4096 + 6144, "valu": 384}
+    return {"f16x3": 4096 + 6144, "f32": 4096 + 6144, "valu": 384}  # activation chain split-fp16, outer products fp32
 
 
 def kernel_roofline(name, ms, n_samples, exact):
@@ -95,9 +95,6 @@ def make_inputs(rank, world, device, config, R=256, Hh=256, Ww=256, S=128):
     for p in prompts:  # per-prompt seed: the global batch does not depend on how it is sharded
         gp = torch.Generator().manual_seed(0 + p)
         caches.append(torch.randn(1, 6, 32, R, R, generator=gp) * 0.5)
-        if p == prompts[0]:
-            sw0 = O.init_mlp_weights([32, 64, 64, 1], gp)
-            fw0 = O.init_mlp_weights([96, 64, 64, 3], gp)
         ro, rd, c2w, cd = O.make_cameras(1, Hh, Ww, azimuth_start_deg=(90.0 if config == 1 else 45.0) * p)
         ros.append(ro), rds.append(rd), c2ws.append(c2w), cds.append(cd)
     # the MLPs are replicated parameters: identical on every rank (seed 0), as DDP guarantees

@@ -86,7 +86,7 @@ if os.path.exists(bj) and os.path.getsize(bj) > 0:
     d = json.loads(line)
     L += ["", "## bench.py line of this build", "",
           f"{d['value'] / 1e6:.3f} M rays/s, {d['ms_per_step']:.2f} ms/step; roofline {d['roofline']['kernel']} "
-          f"{d['roofline']['achieved']} / {d['roofline']['peak']} TFLOP/s = {d['roofline']['frac']}; ray march "
+          f"{d['roofline']['achieved']} / {d['roofline']['peak']} {d['roofline']['unit']} = {d['roofline']['frac']}; ray march "
           f"{d['roofline_hbm']['achieved']} GB/s = {d['roofline_hbm']['frac']} of HBM peak; cpu_baseline "
           f"{d.get('cpu_baseline', {}).get('value', float('nan')):.0f} rays/s on "
           f"{d.get('cpu_baseline', {}).get('cores', '?')} threads."]
