@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
         const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius), Z = scale_coord(pz, cfg.radius);
         float e[48];
-        const bool any = __any(gather_tex(p.packed + pofs, H, W, X, Y, Z, valid, hi, e, cfg.flags));
+        const bool any = __any(gather_tex_c(p.packed, (unsigned)(pofs / TT_C), H, W, X, Y, Z, valid, lane, Xs, e));
         TT_PHASE(1);
         if (!any) continue;  // exact: e == 0 => k1 = k2 = 0 and every mask is false
         // e is needed again only as the Y operand of the dV1 outer product: park it in LDS now ([idx][sample]

@@ -400,6 +400,80 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
     return any;
 }
 
+// ---- coalesced gathers ------------------------------------------------------------------------------------------------
+// The gathers above give every lane its own sample: one wave-instruction touches 32 different 128-byte texel lines, 32
+// bytes of each, and a line is fetched by four instructions.  The L1 / texture-address path, not the latency, is what
+// bounds them (a timing experiment with this access pattern shortened the gather phase by 23 %; issuing all loads at once
+// did nothing).  Here 8 CONSECUTIVE LANES read one texel (lane & 7 = 16-byte chunk): an instruction touches 8 whole lines.
+// The bilinear set-up is still done once per sample in the (sample, half) lane layout and handed over through a small
+// LDS table; lane (js, c) = (lane >> 3, lane & 7) then accumulates channels 4c..4c+3 of samples 8n + js, n = 0..3, in the
+// same corner order as before (bit-identical sums), and the result goes back to the LIDX register layout through a
+// [sample][36]-float LDS tile (conflict-free both ways).
+typedef int ti32x4 __attribute__((ext_vector_type(4)));
+#define GC_TABLE_FLOATS(NW) (3 * 32 * 4 * (1 + (NW))) /* offsets + NW weight sets */
+#define GC_TILE_FLOATS (32 * 36)
+
+// texture planes: e[48] as gather_tex.  T: wave-private LDS scratch, GC_TABLE_FLOATS(1) + GC_TILE_FLOATS floats.
+// `planes` is the base of the packed buffer and `tex0` the texel index of this lane's prompt (a tile may straddle
+// prompts, and the lane that loads a texel is not the lane that owns the sample: the table holds absolute indices).
+__device__ __forceinline__ bool gather_tex_c(const float* __restrict__ planes, unsigned tex0, int H, int W, float X,
+                                             float Y, float Z, bool valid, int lane, float* T, float (&e)[48]) {
+    const int i = lane & 31, hi = lane >> 5, js = lane >> 3, c = lane & 7;
+    int* Toff = reinterpret_cast<int*>(T);
+    float* Tw = T + 3 * 32 * 4;
+    float* R = T + GC_TABLE_FLOATS(1);
+    const size_t HW = (size_t)H * W;
+    bool any = false, anyp[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        Corners cn;
+        corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, cn);
+        anyp[p] = __any(cn.any);
+        any = any || cn.any;
+        if (hi == 0) {
+            const unsigned b = tex0 + (unsigned)((3 + p) * HW);
+            const ti32x4 o = {(int)(b + cn.off[0]), (int)(b + cn.off[1]), (int)(b + cn.off[2]), (int)(b + cn.off[3])};
+            *reinterpret_cast<ti32x4*>(Toff + (p * 32 + i) * 4) = o;
+        } else {
+            const f32x4 w = {cn.w[0], cn.w[1], cn.w[2], cn.w[3]};
+            *reinterpret_cast<f32x4*>(Tw + (p * 32 + i) * 4) = w;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (!anyp[p]) {  // exact: every weight of this plane is 0 for the whole tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[16 * p + r] = 0.f;
+            continue;
+        }
+        const float* pl = planes + 4 * c;
+        f32x4 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int sidx = (p * 32 + 8 * n + js) * 4;
+            const ti32x4 o4 = *reinterpret_cast<const ti32x4*>(Toff + sidx);
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(Tw + sidx);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(pl + (size_t)(unsigned)o4[k] * TT_C);
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) a[ee] = fmaf(w4[k], t[ee], a[ee]);
+            }
+            acc[n] = a;
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(R + (8 * n + js) * 36 + 4 * c) = acc[n];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(R + i * 36 + 4 * (hi + 2 * q));
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) e[16 * p + 4 * q + ee] = v[ee];
+        }
+    }
+    return any;
+}
+
 // ---- work decomposition of the per-sample kernels ----------------------------------------------------------
 // A TILE is 32 samples = RB ADJACENT RAYS x SB CONSECUTIVE SAMPLE INDICES (RB * SB = 32).  SB = 1 (uniform
 // sampling): an 8x4 pixel block at one sample index -- adjacent rays hit neighbouring texels at equal depth, so
