@@ -338,7 +338,6 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
         const int view = (int)(ray / cfg.rays_per_view);
         const size_t pofs = (size_t)(view / cfg.views_per_prompt) * plane_stride;
-        const float* pbase = p.packed + pofs;
         const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
         // rays_d == null: explicit points (tt_points_bwd_*), x = rays_o exactly
         const float dx = p.rays_d ? p.rays_d[ray * 3 + 0] : 0.f, dy = p.rays_d ? p.rays_d[ray * 3 + 1] : 0.f,
@@ -362,10 +361,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                         Z = scale_coord(pz, cfg.radius);
             // ---- recompute the geometry decode ----
             float f[16], u[16];  // u = sbar f + J gbar
-            Corners cs[3];
-            float coefs[3][4];   // per (plane, corner): w sbar + dw/dx . gbar -- gather AND scatter coefficient
-            const bool any = __any(gather_geo_bwd(pbase, H, W, X, Y, Z, rvalid, sbar, gbx, gby, gbz, ju, jv, hi, f, u,
-                                                  cs, coefs, cfg.flags));
+            bool anyp[3];
+            const bool any = __any(gather_geo_bwd_c(p.packed, (unsigned)(pofs / TT_C), H, W, X, Y, Z, rvalid, sbar, gbx,
+                                                    gby, gbz, ju, jv, lane, Xs, f, u, anyp));
             TT_PHASE(1);
             if (!any) continue;  // exact: no in-bounds texel => f = J = 0, every mask false
             float h1[32], h2[32], a2[32], a1[32], q[16];
@@ -391,7 +389,8 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 float qb[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) qb[r] = fmaf(-sbar, f[r], u[r]);  // qbar = J gbar = u - sbar f
-                const bool do_wgrad = !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
+                const bool region = cfg.flags >= 0;  // always true, opaque: see the texture kernel
+                const bool do_wgrad = region && !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
                 // dW1 += a1 (sbar f + qbar)^T
                 if (do_wgrad) {
                     stage_rows<64>(Xs, a1, i, hi);
@@ -424,24 +423,27 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 accw3 += rowsum32(Xs, lane);
                 TT_PHASE(5);
                 // ---- scatter d/d geometry planes: texel(p,c)[ch] += q[ch] * coef(p,c) ----
-                if (!TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
+                if (region && !TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
                     scatter_clear(Xs, lane);  // M = 0 (Xs held wgrad staging)
                     float* Qs = Ys;           // q staged as [sample][32], stride 33 (same for the 3 planes)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) Qs[i * 33 + LIDX(r, hi)] = q[r];
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
-                        if (!__any(cs[pl].any)) continue;  // exact: every coefficient of this plane is 0
+                        if (!anyp[pl]) continue;  // exact: every coefficient of this plane is 0
+                        Corners c;
+                        float coef[4];  // per corner: w sbar + dw/dx . gbar -- gather AND scatter coefficient
+                        geo_corner_coefs(pl, H, W, X, Y, Z, rvalid, sbar, gbx, gby, gbz, ju, jv, c, coef);
                         int aoff[4];
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4)
-                            aoff[q4] = (int)(pofs / TT_C) + (int)(pl * HW) + cs[pl].off[q4];
+                            aoff[q4] = (int)(pofs / TT_C) + (int)(pl * HW) + c.off[q4];
                         TT_PHASE(9);
 #ifdef TT_TUNING
-                        scatter_plane(grad_out, Qs, coefs[pl], aoff, cs[pl].hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags,
+                        scatter_plane(grad_out, Qs, coef, aoff, c.hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags,
                                       ph_acc, &ph_t);
 #else
-                        scatter_plane(grad_out, Qs, coefs[pl], aoff, cs[pl].hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags);
+                        scatter_plane(grad_out, Qs, coef, aoff, c.hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags);
 #endif
                     }
                     TT_PHASE(10);

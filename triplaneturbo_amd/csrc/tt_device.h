@@ -474,6 +474,101 @@ __device__ __forceinline__ bool gather_tex_c(const float* __restrict__ planes, u
     return any;
 }
 
+// corner set-up of one geometry plane and the coefficient  coef_c = w_c sbar + dw_c/dx . gbar  that both the backward
+// gather (u = sum coef_c texel_c) and the gradient scatter use
+__device__ __forceinline__ void geo_corner_coefs(int p, int H, int W, float X, float Y, float Z, bool valid, float sbar,
+                                                 float gux, float guy, float guz, float jscale_u, float jscale_v,
+                                                 Corners& cn, float (&coef)[4]) {
+    corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, cn);
+    const float gu = (p == 2 ? guz : gux) * jscale_u, gv = (p == 1 ? guz : guy) * jscale_v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) coef[k] = fmaf(cn.w[k], sbar, fmaf(cn.du[k], gu, cn.dv[k] * gv));
+}
+
+// geometry planes, backward variant (f and u as gather_geo_bwd, same summation order).  T: GC_TABLE_FLOATS(2) +
+// GC_TILE_FLOATS floats.  Nothing of the corner set-up is kept: the scatter at the end of the tile step re-derives it
+// with geo_corner_coefs (cheap VALU) instead of holding ~40 registers across the MLP chain.
+__device__ __forceinline__ bool gather_geo_bwd_c(const float* __restrict__ planes, unsigned tex0, int H, int W, float X,
+                                                 float Y, float Z, bool valid, float sbar, float gux, float guy,
+                                                 float guz, float jscale_u, float jscale_v, int lane, float* T,
+                                                 float (&f)[16], float (&u)[16], bool (&anyp)[3]) {
+    const int i = lane & 31, hi = lane >> 5, js = lane >> 3, c = lane & 7;
+    int* Toff = reinterpret_cast<int*>(T);
+    float* Tw = T + 3 * 32 * 4;
+    float* Tc = T + 2 * 3 * 32 * 4;
+    float* R = T + GC_TABLE_FLOATS(2);
+    const size_t HW = (size_t)H * W;
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        Corners cn;
+        float coef[4];
+        geo_corner_coefs(p, H, W, X, Y, Z, valid, sbar, gux, guy, guz, jscale_u, jscale_v, cn, coef);
+        anyp[p] = __any(cn.any);
+        any = any || cn.any;
+        if (hi == 0) {
+            const unsigned b = tex0 + (unsigned)(p * HW);
+            const ti32x4 o = {(int)(b + cn.off[0]), (int)(b + cn.off[1]), (int)(b + cn.off[2]), (int)(b + cn.off[3])};
+            *reinterpret_cast<ti32x4*>(Toff + (p * 32 + i) * 4) = o;
+            const f32x4 w = {cn.w[0], cn.w[1], cn.w[2], cn.w[3]};
+            *reinterpret_cast<f32x4*>(Tw + (p * 32 + i) * 4) = w;
+        } else {
+            const f32x4 w = {coef[0], coef[1], coef[2], coef[3]};
+            *reinterpret_cast<f32x4*>(Tc + (p * 32 + i) * 4) = w;
+        }
+    }
+    const float* pl = planes + 4 * c;
+    f32x4 af[4], au[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        af[n] = z;
+        au[n] = z;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (!anyp[p]) continue;  // exact: every weight of this plane is 0 for the whole tile
+        f32x4 t[4][4];  // the 16 loads of a plane are issued back to back (one memory round trip, not four)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const ti32x4 o4 = *reinterpret_cast<const ti32x4*>(Toff + (p * 32 + 8 * n + js) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                t[n][k] = *reinterpret_cast<const f32x4*>(pl + (size_t)(unsigned)o4[k] * TT_C);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int sidx = (p * 32 + 8 * n + js) * 4;
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(Tw + sidx);
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(Tc + sidx);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) {
+                    af[n][ee] = fmaf(w4[k], t[n][k][ee], af[n][ee]);
+                    au[n][ee] = fmaf(c4[k], t[n][k][ee], au[n][ee]);
+                }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(R + (8 * n + js) * 36 + 4 * c) = af[n];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(R + i * 36 + 4 * (hi + 2 * q));
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) f[4 * q + ee] = v[ee];
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(R + (8 * n + js) * 36 + 4 * c) = au[n];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(R + i * 36 + 4 * (hi + 2 * q));
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) u[4 * q + ee] = v[ee];
+    }
+    return any;
+}
+
 // ---- work decomposition of the per-sample kernels ----------------------------------------------------------
 // A TILE is 32 samples = RB ADJACENT RAYS x SB CONSECUTIVE SAMPLE INDICES (RB * SB = 32).  SB = 1 (uniform
 // sampling): an 8x4 pixel block at one sample index -- adjacent rays hit neighbouring texels at equal depth, so
