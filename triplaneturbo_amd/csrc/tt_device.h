@@ -255,7 +255,7 @@ __device__ __forceinline__ float sphere_bias(float px, float py, float pz, float
 #define PLANE_U(p, X, Y, Z) ((p) == 2 ? (Z) : (X))
 #define PLANE_V(p, X, Y, Z) ((p) == 1 ? (Z) : (Y))
 
-// ---- gathers ----------------------------------------------------------------------------------------
+// ---- gathers, one lane per sample (points-gradient and small kernels; the render kernels use the coalesced ones below) ----
 // geometry planes (v1 = sum over planes): f[16] and, if NEED_J, J = d f / d(world xyz) (3 x 16)
 template <bool NEED_J>
 __device__ __forceinline__ bool gather_geo(const float* __restrict__ planes, int H, int W, float X, float Y, float Z,
@@ -314,56 +314,6 @@ __device__ __forceinline__ bool gather_geo(const float* __restrict__ planes, int
     return any;
 }
 
-// backward variant: the upstream (sbar, gbar) of the sample is known before the gather, so the only two
-// combinations of the texels the backward needs are f (for the MLP recompute) and
-//     u = sbar * f + J gbar = sum_corners coef_c * texel_c,   coef_c = w_c sbar + dw_c/dx . gbar
-// (the same coefficient the gradient scatter uses): 32 registers and 2 FMAs per texel value instead of 64 / 4.
-__device__ __forceinline__ bool gather_geo_bwd(const float* __restrict__ planes, int H, int W, float X, float Y,
-                                               float Z, bool valid, float sbar, float gux, float guy, float guz,
-                                               float jscale_u, float jscale_v, int hi, float (&f)[16],
-                                               float (&u)[16], Corners (&cs)[3], float (&coefs)[3][4], int dbg = 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        f[r] = 0.f;
-        u[r] = 0.f;
-    }
-    bool any = false;
-    const size_t HW = (size_t)H * W;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        Corners& c = cs[p];  // kept for the gradient scatter of the same tile
-        corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, c);
-        const float gu = (p == 2 ? guz : gux) * jscale_u, gv = (p == 1 ? guz : guy) * jscale_v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) coefs[p][k] = fmaf(c.w[k], sbar, fmaf(c.du[k], gu, c.dv[k] * gv));
-        if (!__any(c.any)) continue;
-        any = any || c.any;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f32x4* t = reinterpret_cast<const f32x4*>(planes + (p * HW + (size_t)c.off[k]) * TT_C) + hi;
-            f32x4 v[4];
-            if (TT_DBG(dbg, TT_DBG_NO_GATHER)) {
-                const f32x4 z = {c.w[k], c.du[k], c.dv[k], X};
-                v[0] = v[1] = v[2] = v[3] = z;
-            } else {
-                v[0] = t[0];
-                v[1] = t[2];
-                v[2] = t[4];
-                v[3] = t[6];
-            }
-            const float wk = c.w[k], ck = coefs[p][k];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f[4 * q + e] = fmaf(wk, v[q][e], f[4 * q + e]);
-                    u[4 * q + e] = fmaf(ck, v[q][e], u[4 * q + e]);
-                }
-        }
-    }
-    return any;
-}
-
 // texture planes (v2 = concat over planes): e[48], e[16p + r] <-> channel LIDX(r,hi) of plane p
 __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int H, int W, float X, float Y, float Z,
                                            bool valid, int hi, float (&e)[48], int dbg = 0) {
@@ -410,9 +360,158 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
 // same corner order as before (bit-identical sums), and the result goes back to the LIDX register layout through a
 // [sample][36]-float LDS tile (conflict-free both ways).
 typedef int ti32x4 __attribute__((ext_vector_type(4)));
-#define GC_TABLE_FLOATS(NW) (3 * 32 * 4 * (1 + (NW))) /* offsets + NW weight sets */
+#define GC_TABLE_FLOATS(NW) (3 * 32 * 4 * (1 + (NW))) /* 3 planes: offsets + NW weight sets */
 #define GC_TILE_FLOATS (32 * 36)
 
+#define GC_PLANE_TABLE_FLOATS (32 * 16) /* one plane: offsets + up to 3 weight sets */
+#define GC_SCRATCH_FLOATS (GC_PLANE_TABLE_FLOATS + GC_TILE_FLOATS) /* forward kernels: 6.5 KB per wave */
+
+// lane (js, c) loads channels 4c..4c+3 of the 16 texels (4 samples x 4 corners) it serves in plane-table order:
+// the 16 loads are issued back to back -- one memory round trip per plane
+__device__ __forceinline__ void gc_load16(const float* __restrict__ pl, const int* Toff, int js, f32x4 (&t)[4][4]) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const ti32x4 o4 = *reinterpret_cast<const ti32x4*>(Toff + (8 * n + js) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[n][k] = *reinterpret_cast<const f32x4*>(pl + (size_t)(unsigned)o4[k] * TT_C);
+    }
+}
+
+// (js, c) accumulator layout -> LIDX register layout through the [sample][36] tile
+__device__ __forceinline__ void gc_transpose(float* R, const f32x4 (&acc)[4], int i, int hi, int js, int c,
+                                             float* out16) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(R + (8 * n + js) * 36 + 4 * c) = acc[n];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(R + i * 36 + 4 * (hi + 2 * q));
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) out16[4 * q + ee] = v[ee];
+    }
+}
+
+// Forward variants: ONE plane's table at a time (measured faster in the forward kernels, where two waves per SIMD
+// overlap each other's set-up; the backward kernels -- one wave per SIMD -- are faster with all three tables first).
+// T: GC_SCRATCH_FLOATS floats.
+// geometry planes, forward: f[16] and, if NEED_J, J = d f / d(world xyz) (3 x 16), as gather_geo (same sums)
+template <bool NEED_J>
+__device__ __forceinline__ bool gather_geo_c(const float* __restrict__ planes, unsigned tex0, int H, int W, float X,
+                                             float Y, float Z, bool valid, float jscale_u, float jscale_v, int lane,
+                                             float* T, float (&f)[16], float (&jx)[16], float (&jy)[16],
+                                             float (&jz)[16]) {
+    const int i = lane & 31, hi = lane >> 5, js = lane >> 3, c = lane & 7;
+    int* Toff = reinterpret_cast<int*>(T);
+    float* Tw = T + 32 * 4;
+    float* Ta = T + 2 * 32 * 4;
+    float* Tb = T + 3 * 32 * 4;
+    float* R = T + GC_PLANE_TABLE_FLOATS;
+    const size_t HW = (size_t)H * W;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 af[4] = {z4, z4, z4, z4}, ax[4] = {z4, z4, z4, z4}, ay[4] = {z4, z4, z4, z4}, az[4] = {z4, z4, z4, z4};
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        Corners cn;
+        corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, cn);
+        any = any || cn.any;
+        if (!__any(cn.any)) continue;  // exact: every contribution of this plane is 0 for the whole tile
+        if (hi == 0) {
+            const unsigned b = tex0 + (unsigned)(p * HW);
+            const ti32x4 o = {(int)(b + cn.off[0]), (int)(b + cn.off[1]), (int)(b + cn.off[2]), (int)(b + cn.off[3])};
+            *reinterpret_cast<ti32x4*>(Toff + i * 4) = o;
+            const f32x4 w = {cn.w[0], cn.w[1], cn.w[2], cn.w[3]};
+            *reinterpret_cast<f32x4*>(Tw + i * 4) = w;
+        } else if (NEED_J) {
+            const f32x4 a = {cn.du[0] * jscale_u, cn.du[1] * jscale_u, cn.du[2] * jscale_u, cn.du[3] * jscale_u};
+            const f32x4 b = {cn.dv[0] * jscale_v, cn.dv[1] * jscale_v, cn.dv[2] * jscale_v, cn.dv[3] * jscale_v};
+            *reinterpret_cast<f32x4*>(Ta + i * 4) = a;
+            *reinterpret_cast<f32x4*>(Tb + i * 4) = b;
+        }
+        f32x4 t[4][4];
+        gc_load16(planes + 4 * c, Toff, js, t);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(Tw + (8 * n + js) * 4);
+            f32x4 a4 = z4, b4 = z4;
+            if (NEED_J) {
+                a4 = *reinterpret_cast<const f32x4*>(Ta + (8 * n + js) * 4);
+                b4 = *reinterpret_cast<const f32x4*>(Tb + (8 * n + js) * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) {
+                    const float tv = t[n][k][ee];
+                    af[n][ee] = fmaf(w4[k], tv, af[n][ee]);
+                    if (NEED_J) {
+                        if (p == 0) {
+                            ax[n][ee] = fmaf(a4[k], tv, ax[n][ee]);
+                            ay[n][ee] = fmaf(b4[k], tv, ay[n][ee]);
+                        } else if (p == 1) {
+                            ax[n][ee] = fmaf(a4[k], tv, ax[n][ee]);
+                            az[n][ee] = fmaf(b4[k], tv, az[n][ee]);
+                        } else {
+                            az[n][ee] = fmaf(a4[k], tv, az[n][ee]);
+                            ay[n][ee] = fmaf(b4[k], tv, ay[n][ee]);
+                        }
+                    }
+                }
+        }
+    }
+    gc_transpose(R, af, i, hi, js, c, f);
+    if (NEED_J) {
+        gc_transpose(R, ax, i, hi, js, c, jx);
+        gc_transpose(R, ay, i, hi, js, c, jy);
+        gc_transpose(R, az, i, hi, js, c, jz);
+    }
+    return any;
+}
+
+// texture planes, forward: e[48] as gather_tex
+__device__ __forceinline__ bool gather_tex_cp(const float* __restrict__ planes, unsigned tex0, int H, int W, float X,
+                                              float Y, float Z, bool valid, int lane, float* T, float (&e)[48]) {
+    const int i = lane & 31, hi = lane >> 5, js = lane >> 3, c = lane & 7;
+    int* Toff = reinterpret_cast<int*>(T);
+    float* Tw = T + 32 * 4;
+    float* R = T + GC_PLANE_TABLE_FLOATS;
+    const size_t HW = (size_t)H * W;
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        Corners cn;
+        corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, cn);
+        any = any || cn.any;
+        if (!__any(cn.any)) {  // exact: every weight of this plane is 0 for the whole tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[16 * p + r] = 0.f;
+            continue;
+        }
+        if (hi == 0) {
+            const unsigned b = tex0 + (unsigned)((3 + p) * HW);
+            const ti32x4 o = {(int)(b + cn.off[0]), (int)(b + cn.off[1]), (int)(b + cn.off[2]), (int)(b + cn.off[3])};
+            *reinterpret_cast<ti32x4*>(Toff + i * 4) = o;
+        } else {
+            const f32x4 w = {cn.w[0], cn.w[1], cn.w[2], cn.w[3]};
+            *reinterpret_cast<f32x4*>(Tw + i * 4) = w;
+        }
+        f32x4 t[4][4], acc[4];
+        gc_load16(planes + 4 * c, Toff, js, t);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(Tw + (8 * n + js) * 4);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) a[ee] = fmaf(w4[k], t[n][k][ee], a[ee]);
+            acc[n] = a;
+        }
+        gc_transpose(R, acc, i, hi, js, c, &e[16 * p]);
+    }
+    return any;
+}
+
+// Backward variants: all three planes' tables first.
 // texture planes: e[48] as gather_tex.  T: wave-private LDS scratch, GC_TABLE_FLOATS(1) + GC_TILE_FLOATS floats.
 // `planes` is the base of the packed buffer and `tex0` the texel index of this lane's prompt (a tile may straddle
 // prompts, and the lane that loads a texel is not the lane that owns the sample: the table holds absolute indices).
@@ -485,7 +584,11 @@ __device__ __forceinline__ void geo_corner_coefs(int p, int H, int W, float X, f
     for (int k = 0; k < 4; ++k) coef[k] = fmaf(cn.w[k], sbar, fmaf(cn.du[k], gu, cn.dv[k] * gv));
 }
 
-// geometry planes, backward variant (f and u as gather_geo_bwd, same summation order).  T: GC_TABLE_FLOATS(2) +
+// geometry planes, backward variant: the upstream (sbar, gbar) of the sample is known before the gather, so the only
+// two combinations of the texels the backward needs are f (for the MLP recompute) and
+//     u = sbar * f + J gbar = sum_corners coef_c * texel_c,   coef_c = w_c sbar + dw_c/dx . gbar
+// (the same coefficient the gradient scatter uses): 32 registers and 2 FMAs per texel value instead of 64 / 4.
+// Corner order of the sums as in gather_geo.  T: GC_TABLE_FLOATS(2) +
 // GC_TILE_FLOATS floats.  Nothing of the corner set-up is kept: the scatter at the end of the tile step re-derives it
 // with geo_corner_coefs (cheap VALU) instead of holding ~40 registers across the MLP chain.
 __device__ __forceinline__ bool gather_geo_bwd_c(const float* __restrict__ planes, unsigned tex0, int H, int W, float X,

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void k_planes_pack(const float* __restrict__ s
 // per-tile decode (forward): gather -> sdf net (+ input-gradient chain) -> feature net
 // =====================================================================================================
 struct DecodeCfg {
-    const float* pbase;  // packed planes of this prompt: 6 x H x W x 32
+    const float* planes;  // packed planes: n_prompts x 6 x H x W x 32
+    unsigned tex0;        // texel index of this lane's prompt
+    float* T;             // wave-private LDS scratch of the coalesced gathers (GC_SCRATCH_FLOATS)
     int H, W;
     float radius;
     float ju, jv;  // 0.5*W/radius, 0.5*H/radius
@@ -89,7 +91,7 @@ __device__ __forceinline__ void decode_tex_fwd(const float* L, const DecodeCfg& 
                                                bool valid, int i, int hi, float (&c)[3]) {
     c[0] = c[1] = c[2] = 0.f;
     float e[48];
-    bool any = gather_tex(dc.pbase, dc.H, dc.W, X, Y, Z, valid, hi, e, dc.dbg);
+    bool any = gather_tex_cp(dc.planes, dc.tex0, dc.H, dc.W, X, Y, Z, valid, 32 * hi + i, dc.T, e);
     if (TT_DBG(dc.dbg, TT_DBG_NO_MLP)) {
         float t = 0.f;
 #pragma unroll
@@ -115,7 +117,8 @@ __device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& 
     s0 = 0.f;
     gq[0] = gq[1] = gq[2] = 0.f;
     float f[16], jx[16], jy[16], jz[16];
-    bool any = gather_geo<NEED_N>(dc.pbase, dc.H, dc.W, X, Y, Z, valid, dc.ju, dc.jv, hi, f, jx, jy, jz, dc.dbg);
+    bool any = gather_geo_c<NEED_N>(dc.planes, dc.tex0, dc.H, dc.W, X, Y, Z, valid, dc.ju, dc.jv, 32 * hi + i, dc.T, f, jx,
+                                 jy, jz);
     if (TT_DBG(dc.dbg, TT_DBG_NO_MLP)) {
         float t = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
 #pragma unroll
@@ -213,7 +216,8 @@ __device__ __forceinline__ void stage_decode_images(float* L, const MlpPtrs& w) 
 
 template <bool NEED_N, bool NEED_TEX, bool EXACT>
 __global__ __launch_bounds__(DECODE_THREADS) void k_query_points(QueryParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS];
+    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS + (DECODE_THREADS / 64) * GC_SCRATCH_FLOATS];
+    float* T = L + LDS_W16_FLOATS + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
     stage_decode_images<NEED_N, NEED_TEX, EXACT>(L, p.w);
     __syncthreads();
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
@@ -229,7 +233,9 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_query_points(QueryParams p) 
         const bool valid = n < p.n_points;
         const long long idx = (long long)b * p.n_points + (valid ? n : 0);
         DecodeCfg dc;
-        dc.pbase = p.packed + (size_t)(b / p.views_per_prompt) * plane_stride;
+        dc.planes = p.packed;
+        dc.tex0 = (unsigned)((size_t)(b / p.views_per_prompt) * (plane_stride / TT_C));
+        dc.T = T;
         dc.H = p.H;
         dc.W = p.W;
         dc.radius = p.radius;
@@ -280,7 +286,8 @@ struct QueryFieldParams {
 
 template <bool EXACT>
 __global__ __launch_bounds__(256, 2) void k_query_field(QueryFieldParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_FIELD_FLOATS];
+    __shared__ __attribute__((aligned(16))) float L[LDS_FIELD_FLOATS + 4 * GC_SCRATCH_FLOATS];
+    float* T = L + LDS_FIELD_FLOATS + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
     {  // split-fp16 images (tt_mfma16.h), same footprint as the fp32 ones
         MlpPtrs w = p.w;
         stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
@@ -303,11 +310,12 @@ __global__ __launch_bounds__(256, 2) void k_query_field(QueryFieldParams p) {
         const long long n = (tile - (long long)b * tiles_per_batch) * TT_TILE + i;
         const bool valid = n < p.n_points;
         const long long idx = (long long)b * p.n_points + (valid ? n : 0);
-        const float* pbase = p.packed + (size_t)(b / p.views_per_prompt) * plane_stride;
+        const unsigned tex0 = (unsigned)((size_t)(b / p.views_per_prompt) * (plane_stride / TT_C));
         const float px = p.points[idx * 3 + 0], py = p.points[idx * 3 + 1], pz = p.points[idx * 3 + 2];
         const float X = scale_coord(px, p.radius), Y = scale_coord(py, p.radius), Z = scale_coord(pz, p.radius);
         float f[16], jx[16], jy[16], jz[16];
-        const bool any = __any(gather_geo<false>(pbase, p.H, p.W, X, Y, Z, valid, 0.f, 0.f, hi, f, jx, jy, jz));
+        const bool any =
+            __any(gather_geo_c<false>(p.packed, tex0, p.H, p.W, X, Y, Z, valid, 0.f, 0.f, lane, T, f, jx, jy, jz));
         float s0 = 0.f, d[3] = {0.f, 0.f, 0.f};
         if (any) {  // exact skip otherwise: bias-free MLPs of a zero vector
             float h1[32], h2[32];
@@ -359,7 +367,8 @@ struct DecodeRaysParams {
 
 template <bool NEED_N, bool NEED_TEX, bool EXACT>
 __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS];
+    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS + (DECODE_THREADS / 64) * GC_SCRATCH_FLOATS];
+    float* T = L + LDS_W16_FLOATS + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
     stage_decode_images<NEED_N, NEED_TEX, EXACT>(L, p.w);
     __syncthreads();
     const tt_render_cfg& cfg = p.cfg;
@@ -380,7 +389,9 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
         const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
         const int view = (int)(ray / cfg.rays_per_view);
         DecodeCfg dc;
-        dc.pbase = p.packed + (size_t)(view / cfg.views_per_prompt) * plane_stride;
+        dc.planes = p.packed;
+        dc.tex0 = (unsigned)((size_t)(view / cfg.views_per_prompt) * (plane_stride / TT_C));
+        dc.T = T;
         dc.H = cfg.plane_h;
         dc.W = cfg.plane_w;
         dc.radius = cfg.radius;
@@ -452,7 +463,8 @@ struct RenderEvalParams {
 
 template <bool EXACT>
 __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS];
+    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS + (DECODE_THREADS / 64) * GC_SCRATCH_FLOATS];
+    float* T = L + LDS_W16_FLOATS + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
     stage_decode_images<true, true, EXACT>(L, p.w);
     __syncthreads();
     const tt_render_cfg& cfg = p.cfg;
@@ -472,7 +484,9 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
         const long long ray = tile_ray(tg, b, i, ray_ok);
         const int view = (int)(ray / cfg.rays_per_view);
         DecodeCfg dc;
-        dc.pbase = p.packed + (size_t)(view / cfg.views_per_prompt) * plane_stride;
+        dc.planes = p.packed;
+        dc.tex0 = (unsigned)((size_t)(view / cfg.views_per_prompt) * (plane_stride / TT_C));
+        dc.T = T;
         dc.H = cfg.plane_h;
         dc.W = cfg.plane_w;
         dc.radius = cfg.radius;
