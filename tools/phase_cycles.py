@@ -42,7 +42,7 @@ names = ["upstream cbar + skip test", "gather e (12 corners)", "park e in LDS", 
          "ebar_p = V1_p^T k1bar + stage (x3)", "scatter_plane epilogue", "tail",
          "  scatter: slot claims (LDS CAS) + M fill", "  scatter: combine GEMM M Q (fp32 MFMA)",
          "  scatter: flush (predicated 128-byte atomics)", "  scatter: restore M / tags", "  scatter: lost-reference fallback",
-         "", "", ""]
+         "end of tile step -> pop", "item pop (queue atomic)", "ray set-up (issue)"]
 geo_names = ["upstream (d sdf, d sdf_grad) + skip test", "gather f, u (12 corners)", "", "sdf net recompute + reverse chain (5 products)",
              "a1bar = W1 qbar, v", "a2bar = W2 b1bar, dw3 (transpose + VALU)", "", "dW1 outer products",
              "dW2 outer products", "scatter: q staging + corner set-up", "scatter epilogue", "tail",

@@ -136,7 +136,7 @@ __device__ __forceinline__ void scatter_clear(float* M, int lane) {
 }
 
 // One plane of one tile.  Qs[j*33 + ch]: staged per-sample vectors; coef/abs_off/hs: per corner of this lane's sample.
-__device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const float* Qs, const float (&coef)[4], const int (&abs_off)[4], const int (&hs)[4],
+__device__ __forceinline__ void scatter_plane(float* __restrict__ grad, unsigned grad_bytes, const float* Qs, const float (&coef)[4], const int (&abs_off)[4], const int (&hs)[4],
                                               float* M, int* tags, float* Ls, int i, int hi, int flags
 #ifdef TT_TUNING
                                               ,
@@ -186,12 +186,15 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
     }
     TT_PHASE(13);
     // flush: one 128-byte atomic per occupied slot, straight from the accumulators (slot of reg 4g+e = LIDX).
-    // Addresses are a wave-uniform base plus a 32-bit BYTE offset (texel << 7 | channel * 4): one VALU instruction and
-    // the scalar-base form of the atomic instead of four instructions of 64-bit arithmetic per atomic (the host
-    // refuses gradient buffers of 4 GB and more).
+    // BUFFER atomics with a 32-bit BYTE offset (texel << 7 | channel * 4) from the gradient copy: an empty slot's tag
+    // is -1, its offset 0xFFFFFF80 + 4 ch lies beyond num_records (the host refuses gradient buffers of 4 GB - 256 B
+    // and more) and the hardware range check drops the atomic -- no compare, no exec-mask branch per slot (the
+    // predicated global atomics this replaces cost ~100 cycles per slot pair, 12 % of the kernel).
     char* const gbase = reinterpret_cast<char*>(grad);
     const unsigned lane_b = 4u * (unsigned)i;
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(grad, 0, (int)grad_bytes, 0x00020000);
 #define TT_TEXEL_ADDR(T) reinterpret_cast<float*>(gbase + (((unsigned)(T) << 7) | lane_b))
+#define TT_TEXEL_OFF(T) (int)(((unsigned)(T) << 7) | lane_b)
     if (!no_global) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -199,8 +202,8 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
             const i32x4 k1 = *reinterpret_cast<const i32x4*>(tags + 32 + 8 * g + 4 * hi);
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) {
-                if (k0[e2] != -1) atomicAdd(TT_TEXEL_ADDR(k0[e2]), acc0[4 * g + e2]);
-                if (k1[e2] != -1) atomicAdd(TT_TEXEL_ADDR(k1[e2]), acc1[4 * g + e2]);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc0[4 * g + e2], grsrc, TT_TEXEL_OFF(k0[e2]), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc1[4 * g + e2], grsrc, TT_TEXEL_OFF(k1[e2]), 0, 0);
             }
         }
     }
@@ -250,6 +253,7 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ grad, const fl
         }
     }
 #undef TT_TEXEL_ADDR
+#undef TT_TEXEL_OFF
     TT_PHASE(16);
 }
 
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     // tt_planes_unpack_grad.  Spreads same-texel atomics (which serialise at the memory side) over n_copies addresses.
     float* const grad_out =
         p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
+    const unsigned grad_bytes = (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
 
     f32x16 accW1[2][1] = {{ZERO16}, {ZERO16}};
     f32x16 accW2[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};
@@ -440,10 +445,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                             aoff[q4] = (int)(pofs / TT_C) + (int)(pl * HW) + c.off[q4];
                         TT_PHASE(9);
 #ifdef TT_TUNING
-                        scatter_plane(grad_out, Qs, coef, aoff, c.hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags,
+                        scatter_plane(grad_out, grad_bytes, Qs, coef, aoff, c.hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags,
                                       ph_acc, &ph_t);
 #else
-                        scatter_plane(grad_out, Qs, coef, aoff, c.hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags);
+                        scatter_plane(grad_out, grad_bytes, Qs, coef, aoff, c.hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags);
 #endif
                     }
                     TT_PHASE(10);
@@ -530,6 +535,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     const float shrink = cfg.rgb_grad_shrink;
     float* const grad_out =  // private copy of the gradient planes of this workgroup (see k_decode_bwd_geo)
         p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
+    const unsigned grad_bytes = (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
 
     f32x16 accV1a[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};  // dV1[:, 0:64]
     f32x16 accV1b[2][1] = {{ZERO16}, {ZERO16}};                  // dV1[:, 64:96]
@@ -544,7 +550,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     for (;;) {
       long long b;
       int ck;
+      TT_PHASE(17);
       if (!item_pop(iq, tg.order, tg.n_chunks, b, ck)) break;
+      TT_PHASE(18);
         if (b >= tg.n_blocks) continue;  // padding of the ragged last deal round
       bool ray_ok;
       const long long ray = tile_ray(tg, b, i, ray_ok);
@@ -558,6 +566,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
 #pragma unroll
       for (int o = 0; o < 3; ++o) grgb[o] = p.g_rgb ? p.g_rgb[ray * 3 + o] : 0.f;
       const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
+      TT_PHASE(19);
 #pragma nounroll
       for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb) {
         const int si = sb0 + ks;
@@ -693,9 +702,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[16 * pl + r];
 #ifdef TT_TUNING
-                scatter_plane(grad_out, Es, c.w, aoff, c.hs, M, tags, Es + 32 * 33, i, hi, cfg.flags, ph_acc, &ph_t);
+                scatter_plane(grad_out, grad_bytes, Es, c.w, aoff, c.hs, M, tags, Es + 32 * 33, i, hi, cfg.flags, ph_acc, &ph_t);
 #else
-                scatter_plane(grad_out, Es, c.w, aoff, c.hs, M, tags, Es + 32 * 33, i, hi, cfg.flags);
+                scatter_plane(grad_out, grad_bytes, Es, c.w, aoff, c.hs, M, tags, Es + 32 * 33, i, hi, cfg.flags);
 #endif
                 TT_PHASE(10);
             }
@@ -759,7 +768,7 @@ static int debug_flags() {
 
 // the scatter addresses texels with 32-bit byte offsets from the (copy of the) gradient buffer
 static bool grad_buffer_too_large(const tt_render_cfg* cfg) {
-    return (long long)cfg->n_prompts * 6 * cfg->plane_h * cfg->plane_w * TT_C * 4 >= (1LL << 32);
+    return (long long)cfg->n_prompts * 6 * cfg->plane_h * cfg->plane_w * TT_C * 4 >= (1LL << 32) - 256;
 }
 
 // one 4-wave workgroup per CU (register- and LDS-limited), grid a multiple of 8 (XCD chunking)
