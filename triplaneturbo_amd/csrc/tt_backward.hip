@@ -135,126 +135,162 @@ __device__ __forceinline__ void scatter_clear(float* M, int lane) {
     for (int g = 0; g < MS / 4; ++g) *reinterpret_cast<f32x4*>(M + lane * MS + 4 * g) = z;
 }
 
-// One plane of one tile.  Qs[j*33 + ch]: staged per-sample vectors; coef/abs_off/hs: per corner of this lane's sample.
-__device__ __forceinline__ void scatter_plane(float* __restrict__ grad, unsigned grad_bytes, const float* Qs, const float (&coef)[4], const int (&abs_off)[4], const int (&hs)[4],
-                                              float* M, int* tags, float* Ls, int i, int hi, int flags
-#ifdef TT_TUNING
-                                              ,
-                                              unsigned long long* ph_acc = nullptr, unsigned long long* ph_tp = nullptr
-#endif
-) {
-#ifdef TT_TUNING
-    unsigned long long ph_dummy[20], ph_t0 = 0;
-    if (!ph_acc) ph_acc = ph_dummy;
-    unsigned long long& ph_t = ph_tp ? *ph_tp : ph_t0;
-#endif
-    const bool region = flags >= 0;  // always true, opaque to the compiler: see k_decode_bwd_tex
-    const bool no_global = !region || TT_DBG(flags, TT_DBG_NO_GLOBAL_ATOMIC);
-    // ---- claim slots and fill M: lane (i, hi) owns corners 2hi, 2hi+1 of sample i ----
-    int lost = 0, wrote = 0, mine = 0;
+// The three planes of one tile step, software-pipelined.  Everything except the rare lost-reference path is
+// straight-line code (no per-reference branches: inactive references CAS a per-lane dummy tag and store to a dump
+// row of M; empty slots are dropped by the buffer range check), so that plane p's 32 MFMAs (2048 matrix-pipe cycles,
+// one wave per SIMD: nothing else would fill them) run over plane p+1's corner set-up, slot claims and M fill:
+//   operands of plane p -> registers (A = M rows, B = Q columns) ; M back to zero
+//   prep(p+1) ; GEMM(p) || claim(p+1) ; flush(p) from the accumulators ; tags(p) back to empty
+// Tags are double-buffered (the flush of plane p reads them after plane p+1 claimed its slots).
+// LDS per wave: M = 64 rows + 1 dump row (stride MS), tags = 2 x 64 slots + 32 dummies (SCATTER_TAG_INTS).
+#define SCATTER_TAG_INTS 160
+#define SCATTER_M_ROWS 65
+
+struct PlaneRefs {  // the two corners (2hi, 2hi+1) of this lane's sample in one plane
+    float c0, c1;   // coefficient (0: no reference)
+    int o0, o1;     // absolute texel index (prompt and plane included)
+    int h0, h1;     // slot: 8x8 torus hash of the texel coordinates
+};
+__device__ __forceinline__ PlaneRefs plane_refs(const float (&coef)[4], const int (&aoff)[4], const int (&hs)[4],
+                                                int hi) {
+    PlaneRefs r;
+    r.c0 = hi ? coef[2] : coef[0];
+    r.c1 = hi ? coef[3] : coef[1];
+    r.o0 = hi ? aoff[2] : aoff[0];
+    r.o1 = hi ? aoff[3] : aoff[1];
+    r.h0 = hi ? hs[2] : hs[0];
+    r.h1 = hi ? hs[3] : hs[1];
+    return r;
+}
+struct ClaimState {
+    bool w0, w1;  // wrote M (slot won or shared with the same texel)
+    bool m0, m1;  // won the slot: this lane resets the tag
+    bool l0, l1;  // lost the slot to a different texel: direct atomics
+};
+
+__device__ __forceinline__ void scatter_init_tags(int* tags, int lane) {
+    tags[lane] = -1;
+    tags[64 + lane] = -1;
+    if (lane < 32) tags[128 + lane] = -2;  // dummies: never empty, never equal to a texel index
+}
+
+__device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M, int* tg, int* dummy, int i) {
+    ClaimState s;
+    const bool a0 = r.c0 != 0.f, a1 = r.c1 != 0.f;
+    const int old0 = atomicCAS(a0 ? tg + r.h0 : dummy, -1, r.o0);
+    const int old1 = atomicCAS(a1 ? tg + r.h1 : dummy, -1, r.o1);
+    s.m0 = old0 == -1;
+    s.m1 = old1 == -1;
+    s.w0 = s.m0 || old0 == r.o0;
+    s.w1 = s.m1 || old1 == r.o1;
+    s.l0 = a0 && !s.w0;
+    s.l1 = a1 && !s.w1;
+    M[(s.w0 ? r.h0 : 64) * MS + i] = r.c0;
+    M[(s.w1 ? r.h1 : 64) * MS + i] = r.c1;
+    return s;
+}
+
+// references that lost their slot (tile footprint wider than the 8x8 window: sparse rays) go straight to global
+// memory, one half-wave per reference (lanes <-> channels: a coalesced 128-byte atomic each)
+__device__ __forceinline__ void scatter_lost(const PlaneRefs& r, const ClaimState& s, const float* Qs, float* Ls,
+                                             __amdgpu_buffer_rsrc_t grsrc, int i, int hi) {
+    const unsigned long long bal = __ballot(s.l0 || s.l1);
+    if (bal == 0) return;
+    float* Lc = Ls;                                 // [sample][4] coefficient of a lost corner, else 0
+    int* Lo = reinterpret_cast<int*>(Ls + 32 * 4);  // [sample][4] absolute texel index
+    Lc[4 * i + 2 * hi] = s.l0 ? r.c0 : 0.f;
+    Lc[4 * i + 2 * hi + 1] = s.l1 ? r.c1 : 0.f;
+    Lo[4 * i + 2 * hi] = r.o0;
+    Lo[4 * i + 2 * hi + 1] = r.o1;
+    // walk only the samples that lost something, two per step (one per half-wave)
+    unsigned todo = (unsigned)(bal & 0xffffffffull) | (unsigned)(bal >> 32);
+    while (todo) {
+        const int s0 = __builtin_ctz(todo);
+        todo &= todo - 1;
+        int s1 = -1;
+        if (todo) {
+            s1 = __builtin_ctz(todo);
+            todo &= todo - 1;
+        }
+        const int sidx2 = hi ? s1 : s0;
+        if (sidx2 >= 0) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(Lc + 4 * sidx2);
+            const i32x4 o4 = *reinterpret_cast<const i32x4*>(Lo + 4 * sidx2);
+            const float v = Qs[sidx2 * 33 + i];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if ((q >> 1) == hi && coef[q] != 0.f) {
-            int old = -2;
-            if (TT_DBG(flags, TT_DBG_NO_CLAIM)) old = -1;
-            else if (!TT_DBG(flags, TT_DBG_NO_COMBINE)) old = atomicCAS(&tags[hs[q]], -1, abs_off[q]);
-            if (old == -1 || old == abs_off[q]) {
-                M[hs[q] * MS + i] = coef[q];
-                wrote |= 1 << q;
-                if (old == -1) mine |= 1 << q;
-            } else {
-                lost |= 1 << q;
+            for (int q = 0; q < 4; ++q) {
+                const unsigned tex = c4[q] != 0.f ? (unsigned)o4[q] : ~0u;  // ~0: beyond num_records, dropped
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v * c4[q], grsrc, (int)((tex << 7) | (4u * (unsigned)i)),
+                                                                0, 0);
             }
         }
     }
-    lost |= __shfl_xor(lost, 32);
-    TT_PHASE(12);
-    // ---- G = M Q on the matrix cores: the two 32-slot tiles advance as independent accumulator chains ----
-    f32x4 a4[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
-            a4[m][t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
-    f32x16 acc0 = ZERO16, acc1 = ZERO16;
-    if (region && !TT_DBG(flags, TT_DBG_NO_SCATTER_MFMA))
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const float b = Qs[(t + 16 * hi) * 33 + i];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0][t >> 2][t & 3], b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1][t >> 2][t & 3], b, acc1, 0, 0, 0);
-    }
-    TT_PHASE(13);
-    // flush: one 128-byte atomic per occupied slot, straight from the accumulators (slot of reg 4g+e = LIDX).
+}
+
+// prep(pl, refs): corner set-up of plane pl for this lane's sample (and, where Q differs per plane, its staging into
+// Qs[j*33 + ch] -- the previous plane's B operand is in registers by then).  M: all-zero on entry and on exit.
+template <class Prep>
+__device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigned grad_bytes, const float* Qs, float* M,
+                                               int* tags, float* Ls, int i, int hi, Prep&& prep) {
     // BUFFER atomics with a 32-bit BYTE offset (texel << 7 | channel * 4) from the gradient copy: an empty slot's tag
     // is -1, its offset 0xFFFFFF80 + 4 ch lies beyond num_records (the host refuses gradient buffers of 4 GB - 256 B
     // and more) and the hardware range check drops the atomic -- no compare, no exec-mask branch per slot (the
-    // predicated global atomics this replaces cost ~100 cycles per slot pair, 12 % of the kernel).
-    char* const gbase = reinterpret_cast<char*>(grad);
-    const unsigned lane_b = 4u * (unsigned)i;
+    // predicated global atomics this replaced cost ~100 cycles per slot pair, 12 % of the kernel).
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(grad, 0, (int)grad_bytes, 0x00020000);
-#define TT_TEXEL_ADDR(T) reinterpret_cast<float*>(gbase + (((unsigned)(T) << 7) | lane_b))
-#define TT_TEXEL_OFF(T) (int)(((unsigned)(T) << 7) | lane_b)
-    if (!no_global) {
+    const unsigned lane_b = 4u * (unsigned)i;
+    int* const dummy = tags + 128 + i;
+    PlaneRefs rc, rn;
+    ClaimState sc, sn;
+    prep(0, rc);
+    sc = scatter_claim(rc, M, tags, dummy, i);
+    scatter_lost(rc, sc, Qs, Ls, grsrc, i, hi);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        int* const tg = tags + 64 * (pl & 1);
+        // ---- operands of G = M Q into registers; M back to all-zero ----
+        f32x4 a4[2][4];
+        float bq[16];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+                a4[m][t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) bq[t] = Qs[(t + 16 * hi) * 33 + i];
+        M[(sc.w0 ? rc.h0 : 64) * MS + i] = 0.f;
+        M[(sc.w1 ? rc.h1 : 64) * MS + i] = 0.f;
+        if (pl < 2) prep(pl + 1, rn);
+        // ---- the two 32-slot tiles advance as independent accumulator chains; the next plane's claims fill the
+        // matrix-pipe time ----
+        f32x16 acc0 = ZERO16, acc1 = ZERO16;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0][t >> 2][t & 3], bq[t], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1][t >> 2][t & 3], bq[t], acc1, 0, 0, 0);
+        }
+        if (pl < 2) sn = scatter_claim(rn, M, tags + 64 * ((pl + 1) & 1), dummy, i);
+        // ---- flush: one 128-byte atomic per slot pair, straight from the accumulators (slot of reg 4g+e = LIDX) ----
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const i32x4 k0 = *reinterpret_cast<const i32x4*>(tags + 8 * g + 4 * hi);
-            const i32x4 k1 = *reinterpret_cast<const i32x4*>(tags + 32 + 8 * g + 4 * hi);
+            const i32x4 k0 = *reinterpret_cast<const i32x4*>(tg + 8 * g + 4 * hi);
+            const i32x4 k1 = *reinterpret_cast<const i32x4*>(tg + 32 + 8 * g + 4 * hi);
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) {
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc0[4 * g + e2], grsrc, TT_TEXEL_OFF(k0[e2]), 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc1[4 * g + e2], grsrc, TT_TEXEL_OFF(k1[e2]), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc0[4 * g + e2], grsrc,
+                                                                (int)(((unsigned)k0[e2] << 7) | lane_b), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc1[4 * g + e2], grsrc,
+                                                                (int)(((unsigned)k1[e2] << 7) | lane_b), 0, 0);
             }
         }
-    }
-    TT_PHASE(14);
-    // ---- restore the all-zero M and the empty tags for the next plane ----
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if ((wrote >> q) & 1) M[hs[q] * MS + i] = 0.f;
-        if ((mine >> q) & 1) tags[hs[q]] = -1;
-    }
-    TT_PHASE(15);
-    // ---- references that lost their slot (tile footprint wider than the 8x8 window: sparse rays) go straight to
-    // global memory, one half-wave per reference (lanes <-> channels: a coalesced 128-byte atomic each) ----
-    if (__any(lost != 0) && !no_global) {
-        float* Lc = Ls;                                  // [sample][4] coefficient of a lost corner, else 0
-        int* Lo = reinterpret_cast<int*>(Ls + 32 * 4);   // [sample][4] absolute texel index
-        if (hi == 0) {
-            f32x4 c4;
-            i32x4 o4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                c4[q] = ((lost >> q) & 1) ? coef[q] : 0.f;
-                o4[q] = abs_off[q];
-            }
-            *reinterpret_cast<f32x4*>(Lc + 4 * i) = c4;
-            *reinterpret_cast<i32x4*>(Lo + 4 * i) = o4;
-        }
-        // walk only the samples that lost something, two per step (one per half-wave)
-        unsigned todo = (unsigned)(__ballot(lost != 0) & 0xffffffffull);
-        while (todo) {
-            const int s0 = __builtin_ctz(todo);
-            todo &= todo - 1;
-            int s1 = -1;
-            if (todo) {
-                s1 = __builtin_ctz(todo);
-                todo &= todo - 1;
-            }
-            const int sidx2 = hi ? s1 : s0;
-            if (sidx2 >= 0) {
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(Lc + 4 * sidx2);
-                const i32x4 o4 = *reinterpret_cast<const i32x4*>(Lo + 4 * sidx2);
-                const float v = Qs[sidx2 * 33 + i];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (c4[q] != 0.f) atomicAdd(TT_TEXEL_ADDR(o4[q]), v * c4[q]);
-            }
+        // ---- tags of this plane back to empty ----
+        *(sc.m0 ? tg + rc.h0 : dummy) = sc.m0 ? -1 : -2;
+        *(sc.m1 ? tg + rc.h1 : dummy) = sc.m1 ? -1 : -2;
+        if (pl < 2) {
+            scatter_lost(rn, sn, Qs, Ls, grsrc, i, hi);
+            rc = rn;
+            sc = sn;
         }
     }
-#undef TT_TEXEL_ADDR
-#undef TT_TEXEL_OFF
-    TT_PHASE(16);
 }
 
 struct MlpGradPtrs {
@@ -295,7 +331,7 @@ struct BwdGeoParams {
 
 template <bool EXACT>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_GEO16_FLOATS + 4 * (GEO_SCRATCH_FLOATS + 64)];
+    __shared__ __attribute__((aligned(16))) float L[LDS_GEO16_FLOATS + 4 * (GEO_SCRATCH_FLOATS + SCATTER_TAG_INTS)];
     {
         MlpPtrs w = p.w;
         stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
@@ -307,10 +343,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5, wave_in_blk = threadIdx.x >> 6;
-    float* Xs = L + LDS_GEO16_FLOATS + wave_in_blk * (GEO_SCRATCH_FLOATS + 64);
+    float* Xs = L + LDS_GEO16_FLOATS + wave_in_blk * (GEO_SCRATCH_FLOATS + SCATTER_TAG_INTS);
     float* Ys = Xs + 64 * XS;
     int* tags = reinterpret_cast<int*>(Ys + 64 * XS);
-    tags[lane] = -1;
+    scatter_init_tags(tags, lane);
     __syncthreads();
     const int S = cfg.n_samples;
     ItemQueue iq = item_queue(p.queue, tg.n_blocks, tg.n_chunks, tg.unit);
@@ -429,28 +465,21 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 TT_PHASE(5);
                 // ---- scatter d/d geometry planes: texel(p,c)[ch] += q[ch] * coef(p,c) ----
                 if (region && !TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
-                    scatter_clear(Xs, lane);  // M = 0 (Xs held wgrad staging)
-                    float* Qs = Ys;           // q staged as [sample][32], stride 33 (same for the 3 planes)
+                    scatter_clear(Xs, lane);  // M = 0 (Xs held wgrad staging); row 64 (= first row of Ys): dump row
+                    float* Qs = Ys + XS;      // q staged as [sample][32], stride 33 (same for the 3 planes)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) Qs[i * 33 + LIDX(r, hi)] = q[r];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        if (!anyp[pl]) continue;  // exact: every coefficient of this plane is 0
+                    TT_PHASE(9);
+                    const int tex0 = (int)(pofs / TT_C);
+                    scatter_planes(grad_out, grad_bytes, Qs, Xs, tags, Qs + 32 * 33, i, hi, [&](int pl, PlaneRefs& refs) {
                         Corners c;
                         float coef[4];  // per corner: w sbar + dw/dx . gbar -- gather AND scatter coefficient
                         geo_corner_coefs(pl, H, W, X, Y, Z, rvalid, sbar, gbx, gby, gbz, ju, jv, c, coef);
                         int aoff[4];
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4)
-                            aoff[q4] = (int)(pofs / TT_C) + (int)(pl * HW) + c.off[q4];
-                        TT_PHASE(9);
-#ifdef TT_TUNING
-                        scatter_plane(grad_out, grad_bytes, Qs, coef, aoff, c.hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags,
-                                      ph_acc, &ph_t);
-#else
-                        scatter_plane(grad_out, grad_bytes, Qs, coef, aoff, c.hs, Xs, tags, Qs + 32 * 33, i, hi, cfg.flags);
-#endif
-                    }
+                        for (int q4 = 0; q4 < 4; ++q4) aoff[q4] = tex0 + (int)(pl * HW) + c.off[q4];
+                        refs = plane_refs(coef, aoff, c.hs, hi);
+                    });
                     TT_PHASE(10);
                 }
             }
@@ -505,7 +534,7 @@ struct BwdTexParams {
 
 template <bool EXACT>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
-    __shared__ __attribute__((aligned(16))) float Lt[TEX_W16_FLOATS + 4 * (TEX_SCRATCH_FLOATS + 64)];
+    __shared__ __attribute__((aligned(16))) float Lt[TEX_W16_FLOATS + 4 * (TEX_SCRATCH_FLOATS + SCATTER_TAG_INTS)];
     {
         MlpPtrs w = p.w;
         stage_weights<EXACT, 64, 96>(Lt + TV1, w.v1);
@@ -518,14 +547,14 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5, wave_in_blk = threadIdx.x >> 6;
     // per-wave scratch: rows 0..31 = Xs (transposition window / first half of bigger operands), rows 32..127 = Ys
-    float* Xs = Lt + TEX_W16_FLOATS + wave_in_blk * (TEX_SCRATCH_FLOATS + 64);
+    float* Xs = Lt + TEX_W16_FLOATS + wave_in_blk * (TEX_SCRATCH_FLOATS + SCATTER_TAG_INTS);
     float* Ys = Xs + 32 * XS;  // 96 rows: the parked e
     int* tags = reinterpret_cast<int*>(Xs + 128 * XS);
     // cbar of the tile, [3][32]: in the 4 pad columns of Xs rows 0..23 (row r holds floats 4r..4r+3 of the 96) --
     // stage_rows / the scatter matrix only touch columns 0..31 of a row
     float* Cb = Xs + 32;
 #define CB_AT(idx) Cb[((idx) >> 2) * XS + ((idx)&3)]
-    tags[lane] = -1;
+    scatter_init_tags(tags, lane);
     __syncthreads();
     const int S = cfg.n_samples;
     const int H = cfg.plane_h, W = cfg.plane_w;
@@ -684,30 +713,26 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         }
         // ---- ebar = V1^T k1bar (one plane at a time) ; scatter texel(3+p, c)[ch] += w_c * ebar[32p + ch] ----
         if (region && !TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
-            float* M = Xs;              // rows 0..63: the slot x sample coefficient matrix
-            float* Es = Xs + 64 * XS;   // rows 64..: ebar staged as [sample][32], stride 33, then the fallback lists
+            float* M = Xs;              // rows 0..63: the slot x sample coefficient matrix, row 64: dump row
+            float* Es = Xs + SCATTER_M_ROWS * XS;  // ebar staged as [sample][32], stride 33, then the fallback lists
             scatter_clear(M, lane);
             // ebar = V1^T k1bar for the three planes in ONE product (96 rows: k1bar is split into fp16 terms once)
             float eb[48];
             mvtx<EXACT, 96, 64, V1S>(Lt + TV1T, Lt + TV1, kb1, eb, i, hi);
             TT_PHASE(9);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            const int tex0 = (int)(pofs / TT_C);
+            scatter_planes(grad_out, grad_bytes, Es, M, tags, Es + 32 * 33, i, hi, [&](int pl, PlaneRefs& refs) {
                 Corners c;
                 corners_setup(PLANE_U(pl, X, Y, Z), PLANE_V(pl, X, Y, Z), H, W, valid, c);
                 int aoff[4];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4)  // absolute texel index, prompt included
-                    aoff[q4] = (int)(pofs / TT_C) + (int)((3 + pl) * HW) + c.off[q4];
+                    aoff[q4] = tex0 + (int)((3 + pl) * HW) + c.off[q4];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[16 * pl + r];
-#ifdef TT_TUNING
-                scatter_plane(grad_out, grad_bytes, Es, c.w, aoff, c.hs, M, tags, Es + 32 * 33, i, hi, cfg.flags, ph_acc, &ph_t);
-#else
-                scatter_plane(grad_out, grad_bytes, Es, c.w, aoff, c.hs, M, tags, Es + 32 * 33, i, hi, cfg.flags);
-#endif
-                TT_PHASE(10);
-            }
+                refs = plane_refs(c.w, aoff, c.hs, hi);
+            });
+            TT_PHASE(10);
         }
       }
     }
