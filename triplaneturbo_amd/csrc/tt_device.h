@@ -184,7 +184,7 @@ __device__ __forceinline__ float dot_lds(const float* wl, const float (&x)[N / 2
 
 // ---- bilinear corner set-up (ATen GridSampler.cuh:23-31; zeros padding, align_corners=False) -------
 struct Corners {
-    int off[4];   // texel index y*W+x (clamped to 0 when out of bounds)
+    int off[4];   // texel index y*W+x (of the nearest in-bounds texel when out of bounds: weight 0)
     float w[4];   // bilinear weights nw, ne, sw, se (0 when out of bounds)
     float du[4];  // d w / d ix   (0 when out of bounds)
     float dv[4];  // d w / d iy
@@ -194,6 +194,15 @@ struct Corners {
 };
 
 #pragma clang fp contract(off)
+// In-bounds handling WITHOUT lane-mask logic: the textbook form
+//     in_k = bx && by ;  w_k = in_k ? wx * wy : 0 ;  off_k = in_k ? y * W + x : 0
+// compiles to v_cmp -> s_and_b64 (SALU combination of lane masks) -> v_cndmask, and on MI355X that sequence was
+// observed to deliver STALE mask bits for lanes 48..63 to the first select when the SIMD runs a single wave (tail of a
+// kernel): w[2] of the upper half-wave wrong in ~5 of 9375 tiles per launch, nondeterministically, while the offset
+// selected by the same mask two instructions later was right (tools/stress_export.py; gone with s_nop between mask and
+// select, and with -mllvm -amdgpu-waitcnt-forcezero; isolated sequences in tools/sgpr_hazard_probe.hip do not
+// reproduce it).  Here every flag is a float 0/1 made by ONE compare + select (VALU -> VALU through VCC, a hazard hipcc
+// handles) and combined by multiplication; results are bit-identical to the textbook form (x * 1 = x, finite * 0 = 0).
 __device__ __forceinline__ void corners_setup(float gx, float gy, int H, int W, bool valid, Corners& c) {
     // same op order as the reference: ((coord + 1) * size - 1) / 2
     float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
@@ -203,31 +212,37 @@ __device__ __forceinline__ void corners_setup(float gx, float gy, int H, int W, 
     float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
     int x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f);
     int y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
-    bool bx0 = valid && x0 >= 0 && x0 < W, bx1 = valid && x0 + 1 >= 0 && x0 + 1 < W;
-    bool by0 = y0 >= 0 && y0 < H, by1 = y0 + 1 >= 0 && y0 + 1 < H;
-    bool in0 = bx0 && by0, in1 = bx1 && by0, in2 = bx0 && by1, in3 = bx1 && by1;
-    c.w[0] = in0 ? wx0 * wy0 : 0.f;
-    c.w[1] = in1 ? wx1 * wy0 : 0.f;
-    c.w[2] = in2 ? wx0 * wy1 : 0.f;
-    c.w[3] = in3 ? wx1 * wy1 : 0.f;
-    c.du[0] = in0 ? -wy0 : 0.f;
-    c.du[1] = in1 ? wy0 : 0.f;
-    c.du[2] = in2 ? -wy1 : 0.f;
-    c.du[3] = in3 ? wy1 : 0.f;
-    c.dv[0] = in0 ? -wx0 : 0.f;
-    c.dv[1] = in1 ? -wx1 : 0.f;
-    c.dv[2] = in2 ? wx0 : 0.f;
-    c.dv[3] = in3 ? wx1 : 0.f;
-    c.off[0] = in0 ? y0 * W + x0 : 0;
-    c.off[1] = in1 ? y0 * W + x0 + 1 : 0;
-    c.off[2] = in2 ? (y0 + 1) * W + x0 : 0;
-    c.off[3] = in3 ? (y0 + 1) * W + x0 + 1 : 0;
+    x0 = valid ? x0 : -2;  // an invalid lane is out of bounds in x
+    const float bx0 = (unsigned)x0 < (unsigned)W ? 1.f : 0.f, bx1 = (unsigned)(x0 + 1) < (unsigned)W ? 1.f : 0.f;
+    const float by0 = (unsigned)y0 < (unsigned)H ? 1.f : 0.f, by1 = (unsigned)(y0 + 1) < (unsigned)H ? 1.f : 0.f;
+    const float mx0 = wx0 * bx0, mx1 = wx1 * bx1, my0 = wy0 * by0, my1 = wy1 * by1;  // weights masked per axis
+    c.w[0] = mx0 * my0;
+    c.w[1] = mx1 * my0;
+    c.w[2] = mx0 * my1;
+    c.w[3] = mx1 * my1;
+    c.du[0] = -(my0 * bx0);
+    c.du[1] = my0 * bx1;
+    c.du[2] = -(my1 * bx0);
+    c.du[3] = my1 * bx1;
+    c.dv[0] = -(mx0 * by0);
+    c.dv[1] = -(mx1 * by0);
+    c.dv[2] = mx0 * by1;
+    c.dv[3] = mx1 * by1;
+    // texel index: any VALID texel will do for an out-of-bounds corner (its weight, du and dv are 0 and nothing else
+    // looks at it): clamp instead of select
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+    const int yc0 = min(max(y0, 0), H - 1) * W, yc1 = min(max(y0 + 1, 0), H - 1) * W;
+    c.off[0] = yc0 + xc0;
+    c.off[1] = yc0 + xc1;
+    c.off[2] = yc1 + xc0;
+    c.off[3] = yc1 + xc1;
+    const float i0 = bx0 * by0, i1 = bx1 * by0, i2 = bx0 * by1, i3 = bx1 * by1;  // (only the points-gradient kernel)
     c.hs[0] = ((y0 & 7) << 3) | (x0 & 7);
     c.hs[1] = ((y0 & 7) << 3) | ((x0 + 1) & 7);
     c.hs[2] = (((y0 + 1) & 7) << 3) | (x0 & 7);
     c.hs[3] = (((y0 + 1) & 7) << 3) | ((x0 + 1) & 7);
-    c.any = in0 || in1 || in2 || in3;
-    c.inmask = (in0 ? 1 : 0) | (in1 ? 2 : 0) | (in2 ? 4 : 0) | (in3 ? 8 : 0);
+    c.any = (bx0 + bx1) * (by0 + by1) != 0.f;
+    c.inmask = (int)i0 | ((int)i1 << 1) | ((int)i2 << 2) | ((int)i3 << 3);
 }
 
 // world position -> plane-sampling coordinates, mirroring the reference's fp32 op order:
@@ -365,6 +380,14 @@ typedef int ti32x4 __attribute__((ext_vector_type(4)));
 
 #define GC_PLANE_TABLE_FLOATS (32 * 16) /* one plane: offsets + up to 3 weight sets */
 #define GC_SCRATCH_FLOATS (GC_PLANE_TABLE_FLOATS + GC_TILE_FLOATS) /* forward kernels: 6.5 KB per wave */
+
+// texel index -> address of this lane's 16-byte chunk: uniform base + 32-bit BYTE offset (texel << 7 | chunk byte), one
+// VALU instruction and the scalar-base form of the load instead of 64-bit address arithmetic per load (the host
+// refuses packed plane buffers of 4 GB and more: tt_planes_too_large).  Backward kernels only (A/B on one box:
+// backward -0.03 / -0.05 ms, forward +0.09 ms).
+__device__ __forceinline__ const f32x4* gc_addr(const float* __restrict__ planes, int texel, unsigned cbyte) {
+    return reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(planes) + (((unsigned)texel << 7) | cbyte));
+}
 
 // lane (js, c) loads channels 4c..4c+3 of the 16 texels (4 samples x 4 corners) it serves in plane-table order:
 // the 16 loads are issued back to back -- one memory round trip per plane
@@ -545,7 +568,6 @@ __device__ __forceinline__ bool gather_tex_c(const float* __restrict__ planes, u
             for (int r = 0; r < 16; ++r) e[16 * p + r] = 0.f;
             continue;
         }
-        const float* pl = planes + 4 * c;
         f32x4 acc[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -555,7 +577,7 @@ __device__ __forceinline__ bool gather_tex_c(const float* __restrict__ planes, u
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(pl + (size_t)(unsigned)o4[k] * TT_C);
+                const f32x4 t = *gc_addr(planes, o4[k], 16u * (unsigned)c);
 #pragma unroll
                 for (int ee = 0; ee < 4; ++ee) a[ee] = fmaf(w4[k], t[ee], a[ee]);
             }
@@ -620,7 +642,6 @@ __device__ __forceinline__ bool gather_geo_bwd_c(const float* __restrict__ plane
             *reinterpret_cast<f32x4*>(Tc + (p * 32 + i) * 4) = w;
         }
     }
-    const float* pl = planes + 4 * c;
     f32x4 af[4], au[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -637,7 +658,7 @@ __device__ __forceinline__ bool gather_geo_bwd_c(const float* __restrict__ plane
             const ti32x4 o4 = *reinterpret_cast<const ti32x4*>(Toff + (p * 32 + 8 * n + js) * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                t[n][k] = *reinterpret_cast<const f32x4*>(pl + (size_t)(unsigned)o4[k] * TT_C);
+                t[n][k] = *gc_addr(planes, o4[k], 16u * (unsigned)c);
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {

@@ -644,6 +644,11 @@ extern "C" int tt_query_points(const float* packed, const tt_mlp_weights* w, con
     return tt_check_launch();
 }
 
+// the backward gathers address texels with a 32-bit byte offset from the packed buffer
+bool tt_planes_too_large(long long n_prompts, int plane_h, int plane_w) {
+    return n_prompts * 6 * plane_h * plane_w * TT_C * 4 >= (1LL << 32);
+}
+
 int tt_validate_cfg(const tt_render_cfg* cfg) {
     if (!cfg) return TT_ERR_BAD_ARG;
     if (cfg->n_prompts <= 0 || cfg->views_per_prompt <= 0 || cfg->rays_per_view <= 0 || cfg->n_samples <= 0 ||
@@ -651,6 +656,7 @@ int tt_validate_cfg(const tt_render_cfg* cfg) {
         return TT_ERR_BAD_ARG;
     if (cfg->n_rays != (int64_t)cfg->n_prompts * cfg->views_per_prompt * cfg->rays_per_view) return TT_ERR_BAD_ARG;
     if (cfg->plane_h <= 0 || cfg->plane_h != cfg->plane_w) return TT_ERR_UNSUPPORTED;
+    if (tt_planes_too_large(cfg->n_prompts, cfg->plane_h, cfg->plane_w)) return TT_ERR_UNSUPPORTED;
     if (!(cfg->radius > 0.f) || !(cfg->inv_std > 0.f)) return TT_ERR_BAD_ARG;
     if (cfg->flags < 0) return TT_ERR_BAD_ARG;  // (the kernels use `flags >= 0` as an always-true opaque condition)
     return TT_OK;

@@ -7,6 +7,7 @@
 int tt_check_launch();
 int tt_num_cus();
 int tt_validate_cfg(const tt_render_cfg* cfg);
+bool tt_planes_too_large(long long n_prompts, int plane_h, int plane_w);  // packed planes >= 4 GB: unsupported
 
 struct TileGeom;
 // fills the tile geometry / chunking for a render config; returns the number of work items.
