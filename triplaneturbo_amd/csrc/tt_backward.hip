@@ -623,6 +623,15 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         }
         TT_PHASE(0);
         if (!__any(cb[0] != 0.f || cb[1] != 0.f || cb[2] != 0.f)) continue;  // exact: nothing flows back
+#ifdef TT_TUNING
+        {  // live-lane statistics (tools/phase_cycles.py): slots 12 / 13 are unused by the timers
+            const unsigned long long live = __ballot(cb[0] != 0.f || cb[1] != 0.f || cb[2] != 0.f) & 0xffffffffull;
+            const unsigned long long big = __ballot(fabsf(cb[0]) + fabsf(cb[1]) + fabsf(cb[2]) > 1e-12f) & 0xffffffffull;
+            ph_acc[12] += 1;
+            ph_acc[13] += __popcll(live);
+            ph_acc[14] += __popcll(big);
+        }
+#endif
         const float ts = p.rays_d ? p.t_starts[sidx] : 0.f, te = p.rays_d ? p.t_ends[sidx] : 0.f;
         float tm, px, py, pz;
         sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
