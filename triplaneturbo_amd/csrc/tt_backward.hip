@@ -384,20 +384,33 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         const float dx = p.rays_d ? p.rays_d[ray * 3 + 0] : 0.f, dy = p.rays_d ? p.rays_d[ray * 3 + 1] : 0.f,
                     dz = p.rays_d ? p.rays_d[ray * 3 + 2] : 0.f;
         const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
+        // per-step inputs are prefetched one tile step ahead (see k_decode_bwd_tex); a step past the chunk reads a
+        // clamped, valid address
+        struct StepIn {
+            f32x4 up;  // upstream (from the march backward): d/d sdf and d/d sdf_grad of this sample
+            float ts, te;
+        };
+        auto load_step = [&](int sb0) {
+            StepIn r;
+            const int si = sb0 + ks;
+            const long long sidx = ray * S + (si < S ? si : S - 1);
+            r.up = *reinterpret_cast<const f32x4*>(p.ws + sidx * 4);
+            r.ts = p.rays_d ? p.t_starts[sidx] : 0.f;
+            r.te = p.rays_d ? p.t_ends[sidx] : 0.f;
+            return r;
+        };
+        StepIn in = load_step(ck * tg.chunk), in_next;
 #pragma nounroll
-        for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb) {
+        for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb, in = in_next) {
+            in_next = load_step(sb0 + tg.sb);
             const int si = sb0 + ks;
             const bool rvalid = ray_ok && si < s_end;
-            const long long sidx = ray * S + (si < S ? si : S - 1);
-            // upstream (from the march backward): d/d sdf and d/d sdf_grad of this sample
-            f32x4 up = *reinterpret_cast<const f32x4*>(p.ws + sidx * 4);
-            float sbar = rvalid ? up[0] : 0.f, gbx = rvalid ? up[1] : 0.f, gby = rvalid ? up[2] : 0.f,
-                  gbz = rvalid ? up[3] : 0.f;
+            const float sbar = rvalid ? in.up[0] : 0.f, gbx = rvalid ? in.up[1] : 0.f, gby = rvalid ? in.up[2] : 0.f,
+                        gbz = rvalid ? in.up[3] : 0.f;
             TT_PHASE(0);
             if (!__any(sbar != 0.f || gbx != 0.f || gby != 0.f || gbz != 0.f)) continue;  // exact
-            const float ts = p.rays_d ? p.t_starts[sidx] : 0.f, te = p.rays_d ? p.t_ends[sidx] : 0.f;
             float tm, px, py, pz;
-            sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
+            sample_position(ox, oy, oz, dx, dy, dz, in.ts, in.te, tm, px, py, pz);
             const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius),
                         Z = scale_coord(pz, cfg.radius);
             // ---- recompute the geometry decode ----
@@ -596,30 +609,40 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
       for (int o = 0; o < 3; ++o) grgb[o] = p.g_rgb ? p.g_rgb[ray * 3 + o] : 0.f;
       const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
       TT_PHASE(19);
+      // Per-step inputs (weight, features, interval, upstream) are PREFETCHED one tile step ahead: their loads are
+      // issued at the top of the previous step and have landed long before they are needed (they used to cost two
+      // exposed memory round trips per step, 8 % of the kernel; the old "weights first" early-out bought nothing on a
+      // scene where 95 % of the tile steps are live).  A step past the chunk reads a clamped, valid address.
+      struct StepIn {
+          float wgt, f[3], gf[3], ts, te;
+      };
+      auto load_step = [&](int sb0) {
+          StepIn r;
+          const int si = sb0 + ks;
+          const long long sidx = ray * S + (si < S ? si : S - 1);
+          r.wgt = p.weights ? p.weights[sidx] : 0.f;  // null: no march above (points)
+#pragma unroll
+          for (int o = 0; o < 3; ++o) {
+              r.f[o] = p.weights ? p.features[sidx * 3 + o] : 0.f;  // (features only enter through the weights)
+              r.gf[o] = p.g_features ? p.g_features[sidx * 3 + o] : 0.f;
+          }
+          r.ts = p.rays_d ? p.t_starts[sidx] : 0.f;
+          r.te = p.rays_d ? p.t_ends[sidx] : 0.f;
+          return r;
+      };
+      StepIn in = load_step(ck * tg.chunk), in_next;
 #pragma nounroll
-      for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb) {
+      for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb, in = in_next) {
+        in_next = load_step(sb0 + tg.sb);
         const int si = sb0 + ks;
         const bool valid = ray_ok && si < s_end;
-        const long long sidx = ray * S + (si < S ? si : S - 1);
         // ---- upstream: cbar_o = shrink * w_i * g_rgb[ray,o] * 1.002 * s(1-s) + g_features ----
-        // (weights first: a tile whose rays are all dead -- w_i = 0 behind the surface, half of the tile steps of the
-        // bench scene -- is rejected after ONE load per lane, before the features are read and the logistic evaluated)
-        float cb[3] = {0.f, 0.f, 0.f};
-        {
-            const float wgt = (valid && p.weights) ? p.weights[sidx] : 0.f;  // null: no march above (points)
-            if (__any(wgt != 0.f)) {
+        float cb[3];
 #pragma unroll
-                for (int o = 0; o < 3; ++o) {
-                    const float s = sigmoid_(p.features[sidx * 3 + o]);
-                    cb[o] = shrink * wgt * grgb[o] * 1.002f * s * (1.f - s);
-                }
-            }
-            if (p.g_features) {
-#pragma unroll
-                for (int o = 0; o < 3; ++o) cb[o] += p.g_features[sidx * 3 + o];
-            }
-#pragma unroll
-            for (int o = 0; o < 3; ++o) cb[o] = valid ? cb[o] : 0.f;
+        for (int o = 0; o < 3; ++o) {
+            const float s = sigmoid_(in.f[o]);
+            const float c = shrink * in.wgt * grgb[o] * 1.002f * s * (1.f - s) + in.gf[o];
+            cb[o] = valid ? c : 0.f;
         }
         TT_PHASE(0);
         if (!__any(cb[0] != 0.f || cb[1] != 0.f || cb[2] != 0.f)) continue;  // exact: nothing flows back
@@ -632,9 +655,8 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             ph_acc[14] += __popcll(big);
         }
 #endif
-        const float ts = p.rays_d ? p.t_starts[sidx] : 0.f, te = p.rays_d ? p.t_ends[sidx] : 0.f;
         float tm, px, py, pz;
-        sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
+        sample_position(ox, oy, oz, dx, dy, dz, in.ts, in.te, tm, px, py, pz);
         const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius), Z = scale_coord(pz, cfg.radius);
         float e[48];
         const bool any = __any(gather_tex_c(p.packed, (unsigned)(pofs / TT_C), H, W, X, Y, Z, valid, lane, Xs, e));
