@@ -228,8 +228,9 @@ int tt_march_bwd(const float* rays_d, const float* t_starts, const float* t_ends
  * Per-sample upstream grads (null = 0): g_weights, g_sdf, g_sdf_grad(3).
  * Saved forward state: opacity, depth (per ray), trans, sdf, sdf_grad, features (per sample).
  * workspace: n_rays*S*4 floats (written by the march backward, read by the decode backward).
- * grad_packed (P,6,H,W,32) and mlp grads are accumulated into (caller zero-fills); one copy of grad_packed must be
- * smaller than 4 GB (85 prompts of 256^2 planes), else TT_ERR_UNSUPPORTED. */
+ * grad_packed (P,6,H,W,32) and mlp grads are accumulated into (caller zero-fills).  The packed planes (= one copy of
+ * grad_packed) must be smaller than 4 GB - 256 B (85 prompts of 256^2 planes), else TT_ERR_UNSUPPORTED -- the limit
+ * applies to every entry point that takes a tt_render_cfg or a packed-planes pointer (32-bit texel byte offsets). */
 int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, const float* rays_o, const float* rays_d,
                       const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, const float* opacity,
                       const float* depth, const float* trans, const float* sdf, const float* sdf_grad,
