@@ -216,6 +216,12 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.tt_decode_rays(one, ctypes.byref(w), one, one, one, one, ctypes.byref(cfg), 1, one, null, null,
                               null) == -1  # TT_Q_NORMAL without an sdf_grad buffer
     assert lib.tt_grid_sample_2d_grad2(one, one, one, one, one, 1, 4, 8, 8, 5, 1, 0, one, one, one, null) == -2
+    # packed planes of 4 GB and more (texels are addressed with 32-bit byte offsets): 86 prompts x 6 x 256^2 x 128 B
+    big = _lib.RenderCfg(86, 1, 256, 256, 16, 4, 86 * 16, 1.0, 0.5, 100.0, 1.0, 1.0, 0, 0, 0, 1)
+    ok = _lib.RenderCfg(85, 1, 256, 256, 16, 4, 85 * 16, 1.0, 0.5, 100.0, 1.0, 1.0, 0, 0, 0, 1)
+    assert lib.tt_render_fwd(one, ctypes.byref(w), one, one, one, one, ctypes.byref(big), *args, null) == -2
+    assert lib.tt_render_fwd(one, ctypes.byref(w), one, one, one, one, ctypes.byref(ok), *([null] + [one] * 10),
+                             null) == -1  # passes the size check, then fails on the null output
     assert b"unsupported" in lib.tt_strerror(-2)
 
 
