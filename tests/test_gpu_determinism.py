@@ -102,3 +102,30 @@ def test_training_step_gradients_spread_only_by_summation_order():
         assert torch.equal(rgb, ref_rgb), it  # the forward has no atomics: bit-identical
         for a, b in zip(ref, cur):
             assert ((a - b).abs().max() / a.abs().max()).item() < 2e-5, it
+
+
+def test_eval_render_and_field_query_are_bitwise_reproducible():
+    """The fused eval renderer (ballot-based early termination) and the implicit-field query have no atomics either."""
+    from triplaneturbo_amd import ops
+    dev, cache, sw, fw, _ = _setup(seed=10, n_v=64)
+    packed = ops.planes_pack(cache.to(dev))
+    swd, fwd = [w.to(dev) for w in sw], [w.to(dev) for w in fw]
+    gen = torch.Generator().manual_seed(3)
+    dw = [w.to(dev) for w in O.init_mlp_weights([32, 64, 64, 3], gen)]
+    Hh = Ww = 96
+    ro, rd, c2w, cd = [t.to(dev) for t in O.make_cameras(1, Hh, Ww)]
+    ts, te = [t.to(dev) for t in O.uniform_intervals(Hh * Ww, 64, 0.3, 3.2)]
+    pts = (torch.rand(1, 200_000, 3, generator=gen) * 2 - 1).to(dev)
+    ref = None
+    for it in range(8):
+        ev = ops.render_eval_raw(packed, swd, fwd, ro.reshape(-1, 3), rd.reshape(-1, 3), ts, te, Hh * Ww,
+                                 ops.RenderConfig(), image_w=Ww, transmittance_eps=1e-4, weight_eps=1e-6)
+        sdf, deform = ops.query_field(packed, swd, dw, pts)
+        torch.cuda.synchronize()
+        cur = {k: ev[k].clone() for k in ("opacity", "depth", "rgb_fg", "normal_acc")}
+        cur["field_sdf"], cur["field_deform"] = sdf.clone(), deform.clone()
+        if ref is None:
+            ref = cur
+            continue
+        for k in ref:
+            assert torch.equal(ref[k], cur[k]), (it, k)
