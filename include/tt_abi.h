@@ -53,7 +53,8 @@
  *   tt_hashgrid_fwd / _bwd  tiny-cuda-nn's `HashGrid` encoding as used by the background
  *                           (multi_prompt_neural_environment_hashgrid_map_background.py:25-34,54,104-105 via
  *                           threestudio/models/networks.py:17-26,54-64); tcnn is CUDA-only and un-vendored.
- *   tt_grid_sample_2d_grad2 gridsample_cuda.cpp:26-37 `grad2_2d` itself (operator-level drop-in).
+ *   tt_grid_sample_2d_grad2 gridsample_cuda.cpp:26-37 `grad2_2d` itself (operator-level drop-in; _typed: half / float /
+ *   (_typed)                double, zeros / border padding, either align_corners, as gridsample_cuda.cu:560-594).
  */
 #ifndef TT_ABI_H
 #define TT_ABI_H
@@ -64,7 +65,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 9
+#define TT_ABI_VERSION 10
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -323,10 +324,21 @@ int tt_composite_bwd(const float* opacity, const float* depth, const float* rgb_
                      float* g_normal_acc, float* g_bg, void* stream);
 
 /* Operator-level drop-in for the reference's pybind op `gridsample_grad2.grad2_2d`
- * (gridsample_cuda.cpp:26-37): backward of aten::grid_sampler_2d_backward, bilinear.  Contiguous fp32:
- * input / grad2_grad_input / grad_input (n,c,h,w); grid / grad2_grad_grid / grad_grid (n,Ho,Wo,2);
- * grad_output / grad_grad_output (n,c,Ho,Wo); n_points_per_batch = Ho*Wo.  padding_mode 0 = zeros and
- * align_corners = 0 only (TT_ERR_UNSUPPORTED otherwise).  grad_input is zero-filled inside (like the reference). */
+ * (gridsample_cuda.cpp:26-37; dispatch gridsample_cuda.cu:560-594): backward of aten::grid_sampler_2d_backward,
+ * bilinear.  Contiguous tensors of one dtype: input / grad2_grad_input / grad_input (n,c,h,w); grid / grad2_grad_grid /
+ * grad_grid (n,Ho,Wo,2); grad_output / grad_grad_output (n,c,Ho,Wo); n_points_per_batch = Ho*Wo.
+ * padding_mode 0 = zeros, 1 = border (the reference passes it as a bool); align_corners 0 / 1; dtype TT_DTYPE_*
+ * (half computes in fp32).  Reflection padding and the 3-D variant are TT_ERR_UNSUPPORTED / not exported (the
+ * reference never calls them).  grad_input is zero-filled inside (like the reference).
+ * tt_grid_sample_2d_grad2 is the fp32 entry point. */
+#define TT_DTYPE_F32 0
+#define TT_DTYPE_F16 1
+#define TT_DTYPE_F64 2
+int tt_grid_sample_2d_grad2_typed(int32_t dtype, const void* grad2_grad_input, const void* grad2_grad_grid,
+                                  const void* grad_output, const void* input, const void* grid, int32_t n, int32_t c,
+                                  int32_t h, int32_t w, int64_t n_points_per_batch, int32_t padding_mode,
+                                  int32_t align_corners, void* grad_grad_output, void* grad_input, void* grad_grid,
+                                  void* stream);
 int tt_grid_sample_2d_grad2(const float* grad2_grad_input, const float* grad2_grad_grid, const float* grad_output,
                             const float* input, const float* grid, int32_t n, int32_t c, int32_t h, int32_t w,
                             int64_t n_points_per_batch, int32_t padding_mode, int32_t align_corners,

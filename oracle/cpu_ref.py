@@ -81,17 +81,27 @@ def project_onto_planes(coordinates: Tensor) -> Tensor:
     )
 
 
-def bilinear_corners(grid: Tensor, H: int, W: int):
-    """ATen GridSampler (align_corners=False, zeros padding) index math,
-    aten/src/ATen/native/cuda/GridSampler.cuh:23-31 and
-    gridsample_cuda.cu:87-129 (same formulas).
+def bilinear_corners(grid: Tensor, H: int, W: int, padding_mode: str = "zeros", align_corners: bool = False):
+    """ATen GridSampler index math (aten/src/ATen/native/cuda/GridSampler.cuh:23-31, GridSampler.h
+    grid_sampler_unnormalize / clip_coordinates; gridsample_cuda.cu:87-129 uses the same formulas).  The renderer
+    path uses the defaults (zeros padding, align_corners=False); "border" clips the pixel coordinate to
+    [0, size-1] (gradient 0 outside), align_corners=True maps -1/+1 to the centres of the corner pixels.
 
     grid (..., 2) with [...,0] -> W axis.  Returns a list of 4 corners
-    (iy, ix, weight, in_bounds) in the order nw, ne, sw, se, plus (ix, iy).
+    (iy, ix, weight, in_bounds) in the order nw, ne, sw, se.
     """
     gx, gy = grid[..., 0], grid[..., 1]
-    ix = ((gx + 1) * W - 1) / 2
-    iy = ((gy + 1) * H - 1) / 2
+    if align_corners:
+        ix = ((gx + 1) / 2) * (W - 1)
+        iy = ((gy + 1) / 2) * (H - 1)
+    else:
+        ix = ((gx + 1) * W - 1) / 2
+        iy = ((gy + 1) * H - 1) / 2
+    if padding_mode == "border":
+        ix = ix.clamp(0, W - 1)
+        iy = iy.clamp(0, H - 1)
+    elif padding_mode != "zeros":
+        raise ValueError(padding_mode)
     ix_nw = torch.floor(ix)
     iy_nw = torch.floor(iy)
     ix_ne, iy_ne = ix_nw + 1, iy_nw
@@ -108,10 +118,9 @@ def bilinear_corners(grid: Tensor, H: int, W: int):
     return corners
 
 
-def grid_sample_gather(inp: Tensor, grid: Tensor) -> Tensor:
-    """Gather-based restatement of F.grid_sample(mode='bilinear',
-    padding_mode='zeros', align_corners=False)
-    (custom/triplaneturbo/models/geometry/utils.py:21-24).
+def grid_sample_gather(inp: Tensor, grid: Tensor, padding_mode: str = "zeros", align_corners: bool = False) -> Tensor:
+    """Gather-based restatement of F.grid_sample(mode='bilinear', padding_mode, align_corners); the renderer uses
+    padding_mode='zeros', align_corners=False (custom/triplaneturbo/models/geometry/utils.py:21-24).
 
     Built from differentiable indexing so that autograd provides first AND
     second order derivatives on CPU (stock torch has no double backward for
@@ -123,7 +132,7 @@ def grid_sample_gather(inp: Tensor, grid: Tensor) -> Tensor:
     N, C, H, W = inp.shape
     flat = inp.permute(0, 2, 3, 1).reshape(N, H * W, C)
     out = None
-    for cy, cx, w, inb in bilinear_corners(grid, H, W):
+    for cy, cx, w, inb in bilinear_corners(grid, H, W, padding_mode, align_corners):
         idx = (cy.clamp(0, H - 1) * W + cx.clamp(0, W - 1)).long()  # (N, M)
         val = torch.gather(flat, 1, idx[..., None].expand(-1, -1, C))
         val = val * inb[..., None].to(inp.dtype)

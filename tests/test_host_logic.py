@@ -164,7 +164,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == 9
+    assert lib.tt_abi_version() == 10
     assert b"bad argument" in lib.tt_strerror(-1)
 
 
@@ -215,7 +215,8 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
                              null) == -1
     assert lib.tt_decode_rays(one, ctypes.byref(w), one, one, one, one, ctypes.byref(cfg), 1, one, null, null,
                               null) == -1  # TT_Q_NORMAL without an sdf_grad buffer
-    assert lib.tt_grid_sample_2d_grad2(one, one, one, one, one, 1, 4, 8, 8, 5, 1, 0, one, one, one, null) == -2
+    assert lib.tt_grid_sample_2d_grad2(one, one, one, one, one, 1, 4, 8, 8, 5, 2, 0, one, one, one, null) == -2  # reflection
+    assert lib.tt_grid_sample_2d_grad2_typed(7, one, one, one, one, one, 1, 4, 8, 8, 5, 0, 0, one, one, one, null) == -2
     # packed planes of 4 GB and more (texels are addressed with 32-bit byte offsets): 86 prompts x 6 x 256^2 x 128 B
     big = _lib.RenderCfg(86, 1, 256, 256, 16, 4, 86 * 16, 1.0, 0.5, 100.0, 1.0, 1.0, 0, 0, 0, 1)
     ok = _lib.RenderCfg(85, 1, 256, 256, 16, 4, 85 * 16, 1.0, 0.5, 100.0, 1.0, 1.0, 0, 0, 0, 1)

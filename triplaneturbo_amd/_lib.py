@@ -24,7 +24,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomic
 # every symbol include/tt_abi.h declares (tests check the header and this list agree)
 SYMBOLS = [
     "tt_strerror", "tt_abi_version", "tt_planes_pack", "tt_planes_unpack_grad", "tt_query_points",
-    "tt_query_field", "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2",
+    "tt_query_field", "tt_decode_rays", "tt_render_fwd", "tt_render_bwd_geo", "tt_render_bwd_tex", "tt_grid_sample_2d_grad2", "tt_grid_sample_2d_grad2_typed",
     "tt_march_fwd", "tt_march_bwd", "tt_sample_uniform", "tt_sample_importance",
     "tt_points_bwd_geo", "tt_points_bwd_tex", "tt_points_bwd_x", "tt_hashgrid_n_params", "tt_hashgrid_fwd", "tt_hashgrid_bwd",
     "tt_debug_poison_queue", "tt_patch_composite_fwd", "tt_patch_composite_bwd", "tt_render_eval",
@@ -154,6 +154,7 @@ def load() -> ctypes.CDLL:
         "tt_sample_uniform": [_I64, _I32, _F, _F, _P, _P, _P, _P],
         "tt_sample_importance": [_P, _P, _P, _I64, _I32, _I32, _F, _F, _P, _P, _P, _P],
         "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
+        "tt_grid_sample_2d_grad2_typed": [_I32] + [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
         "tt_debug_poison_queue": [_P],
         "tt_composite_fwd": [_P, _P, _P, _P, _P, _I32, _P, _P, _I64, _I32, _I32, _I32] + [_P] * 6,
         "tt_composite_bwd": [_P, _P, _P, _P, _P, _I32, _P, _P, _I64, _I32, _I32, _I32] + [_P] * 11,

@@ -17,22 +17,29 @@ def grid_sample_2d(input, grid, padding_mode="zeros", align_corners=False):
     return _GridSample2dForward.apply(input, grid, padding_mode, align_corners)
 
 
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}  # TT_DTYPE_* (include/tt_abi.h)
+
+
 def grad2_2d(grad2_grad_input, grad2_grad_grid, grad_output, input, grid, padding_mode, align_corners):
-    """gridsample_cuda.cpp:26-37 signature; returns [grad_grad_output, grad_input, grad_grid]."""
-    input = _chk(input, "input")
-    grid = _chk(grid, "grid")
-    grad_output = _chk(grad_output, "grad_output")
-    g2i = _chk(grad2_grad_input, "grad2_grad_input", input.shape)
-    g2g = _chk(grad2_grad_grid, "grad2_grad_grid", grid.shape)
+    """gridsample_cuda.cpp:26-37 signature; returns [grad_grad_output, grad_input, grad_grid].  half / float / double,
+    padding_mode 0 (zeros) or 1 (border) -- the reference passes it as a bool --, either align_corners."""
+    dt = input.dtype
+    if dt not in _DTYPES:
+        raise TypeError(f"grad2_2d: unsupported dtype {dt}")
+    input = _chk(input, "input", dtype=dt)
+    grid = _chk(grid, "grid", dtype=dt)
+    grad_output = _chk(grad_output, "grad_output", dtype=dt)
+    g2i = _chk(grad2_grad_input, "grad2_grad_input", input.shape, dtype=dt)
+    g2g = _chk(grad2_grad_grid, "grad2_grad_grid", grid.shape, dtype=dt)
     N, C, H, W = input.shape
     M = grid.shape[1] * grid.shape[2]
     ggo = torch.empty_like(grad_output)
     gi = torch.empty_like(input)
     gg = torch.empty_like(grid)
-    st = _lib.load().tt_grid_sample_2d_grad2(_ptr(g2i), _ptr(g2g), _ptr(grad_output), _ptr(input), _ptr(grid), N, C, H,
-                                             W, M, int(padding_mode), int(bool(align_corners)), _ptr(ggo), _ptr(gi),
-                                             _ptr(gg), _stream())
-    _lib.check(st, "tt_grid_sample_2d_grad2")
+    st = _lib.load().tt_grid_sample_2d_grad2_typed(_DTYPES[dt], _ptr(g2i), _ptr(g2g), _ptr(grad_output), _ptr(input),
+                                                   _ptr(grid), N, C, H, W, M, int(padding_mode),
+                                                   int(bool(align_corners)), _ptr(ggo), _ptr(gi), _ptr(gg), _stream())
+    _lib.check(st, "tt_grid_sample_2d_grad2_typed")
     return [ggo, gi, gg]
 
 

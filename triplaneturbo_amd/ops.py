@@ -69,13 +69,13 @@ def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _chk(t: Tensor, name: str, shape: Optional[Sequence[int]] = None) -> Tensor:
+def _chk(t: Tensor, name: str, shape: Optional[Sequence[int]] = None, dtype=torch.float32) -> Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a tensor")
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (triplaneturbo_amd has no CPU path)")
-    if t.dtype != torch.float32:
-        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
     if t.device.index != torch.cuda.current_device():
         # the kernels run on the current device's current stream (one process per GPU): a tensor of another GPU
         # would be a wild pointer there
