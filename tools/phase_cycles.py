@@ -1,5 +1,5 @@
 """Dev tool (tuning build): where do the cycles of k_decode_bwd_tex go?  s_memtime stamps between the phases of a tile
-step, summed over all waves of the bench workload.  usage: python tools/phase_cycles.py"""
+step, summed over all waves of the bench workload.  usage: python tools/phase_cycles.py [training]"""
 import ctypes
 import os
 import sys
@@ -14,17 +14,43 @@ import bench  # noqa: E402
 from triplaneturbo_amd import functional, ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
-inp = bench.make_inputs(0, 1, dev, 1)
-rc = ops.RenderConfig()
-params = [inp["cache"]] + inp["sw"] + inp["fw"]
+if len(sys.argv) > 1 and sys.argv[1] == "training":
+    # the reference's training shapes: 2 prompts x 4 views, PatchRenderer 42^2 + 40^2 rays, 128 + 64 importance samples
+    import triplaneturbo_amd as tt
+    from triplaneturbo_amd import synthetic
+    torch.manual_seed(0)
+    geo = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
+    base = dict(estimator="importance", trainable_variance=False, learned_variance_init=0.4605, num_samples_per_ray=64,
+                num_samples_per_ray_importance=128, near_plane=0.1, far_plane=4.0, randomized=True)
+    rend = tt.find("patch-renderer")({"patch_size": 40, "global_downsample": 3,
+                                      "base_renderer_type": "generative-space-sdf-volume-renderer",
+                                      "base_renderer": base}, geometry=geo, material=tt.find("no-material")({}),
+                                     background=tt.find("solid-color-background")({})).to(dev)
+    rend.train()
+    gen = torch.Generator().manual_seed(1)
+    cache = (torch.randn(2, 6, 32, 256, 256, generator=gen) * 0.5).to(dev).requires_grad_(True)
+    ro, rd, c2w, cd = synthetic.make_cameras(8, 128, 128)
+    kw = dict(space_cache=cache, text_embed=torch.zeros(2, 77, 1024), camera_distances=cd.to(dev), c2w=c2w.to(dev))
+    ro, rd, bgc = ro.to(dev), rd.to(dev), torch.ones(3, device=dev)
 
+    def step():
+        out = rend(ro, rd, None, bgc, **kw)
+        loss = out["comp_rgb"].mean() + (out["opacity"] ** 2 + 0.01).sqrt().mean() + \
+            ((out["sdf_grad"].norm(dim=-1) - 1) ** 2).mean()
+        for p_ in [cache] + list(geo.parameters()):
+            p_.grad = None
+        loss.backward()
+else:
+    inp = bench.make_inputs(0, 1, dev, 1)
+    rc = ops.RenderConfig()
+    params = [inp["cache"]] + inp["sw"] + inp["fw"]
 
-def step():
-    for t in params:
-        t.grad = None
-    out = functional.volume_render(inp["cache"], inp["sw"], inp["fw"], inp["ro"], inp["rd"], inp["ts"], inp["te"],
-                                   inp["bg"], inp["cd"], inp["c2w"], rc, training=True)
-    bench.loss_fn(out, inp["proj"]).backward()
+    def step():
+        for t in params:
+            t.grad = None
+        out = functional.volume_render(inp["cache"], inp["sw"], inp["fw"], inp["ro"], inp["rd"], inp["ts"], inp["te"],
+                                       inp["bg"], inp["cd"], inp["c2w"], rc, training=True)
+        bench.loss_fn(out, inp["proj"]).backward()
 
 
 lib = _lib.load()

@@ -24,6 +24,10 @@ r = tt.find("patch-renderer")({"patch_size": 40, "global_downsample": 3,
                               geometry=g, material=tt.find("no-material")({}),
                               background=tt.find("solid-color-background")({})).to(dev)
 r.train()
+if os.environ.get("TT_SB_IMPORTANCE"):  # sweep of the tile shape used under importance sampling
+    for m in r.modules():
+        if hasattr(m, "tile_sb_importance"):
+            m.tile_sb_importance = int(os.environ["TT_SB_IMPORTANCE"])
 gen = torch.Generator().manual_seed(1)
 cache = (torch.randn(P, 6, 32, 256, 256, generator=gen) * 0.5).to(dev).requires_grad_(True)
 ro, rd, c2w, cd = synthetic.make_cameras(P * NV, 128, 128)
