@@ -174,6 +174,9 @@ __device__ __forceinline__ void scatter_init_tags(int* tags, int lane) {
     if (lane < 32) tags[128 + lane] = -2;  // dummies: never empty, never equal to a texel index
 }
 
+#ifdef TT_TUNING
+__device__ unsigned long long g_scatter_stats[4];  // [0] active references, [1] lost references, [2] plane-tiles
+#endif
 __device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M, int* tg, int* dummy, int i) {
     ClaimState s;
     const bool a0 = r.c0 != 0.f, a1 = r.c1 != 0.f;
@@ -187,6 +190,17 @@ __device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M
     s.l1 = a1 && !s.w1;
     M[(s.w0 ? r.h0 : 64) * MS + i] = r.c0;
     M[(s.w1 ? r.h1 : 64) * MS + i] = r.c1;
+#ifdef TT_TUNING
+    {
+        const int na = __popcll(__ballot(a0)) + __popcll(__ballot(a1));
+        const int nl = __popcll(__ballot(s.l0)) + __popcll(__ballot(s.l1));
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&g_scatter_stats[0], (unsigned long long)na);
+            atomicAdd(&g_scatter_stats[1], (unsigned long long)nl);
+            atomicAdd(&g_scatter_stats[2], 1ull);
+        }
+    }
+#endif
     return s;
 }
 
@@ -846,6 +860,16 @@ extern "C" int tt_tuning_phase_cycles(unsigned long long* out40) {
     if (hipDeviceSynchronize() != hipSuccess) return -4;
     if (out40 && hipMemcpy(out40, g_phase_cycles, 40 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
         return -4;
+    {  // scatter statistics ride in the three unused slots at the end
+        unsigned long long st[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
+        if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_scatter_stats), sizeof(st)) != hipSuccess) return -4;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_scatter_stats), zero, sizeof(zero)) != hipSuccess) return -4;
+        if (out40) {
+            out40[37] = st[0];
+            out40[38] = st[1];
+            out40[39] = st[2];
+        }
+    }
     return hipMemset(g_phase_cycles, 0, 40 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
 }
 #endif
