@@ -419,8 +419,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             in_next = load_step(sb0 + tg.sb);
             const int si = sb0 + ks;
             const bool rvalid = ray_ok && si < s_end;
-            const float sbar = rvalid ? in.up[0] : 0.f, gbx = rvalid ? in.up[1] : 0.f, gby = rvalid ? in.up[2] : 0.f,
-                        gbz = rvalid ? in.up[3] : 0.f;
+            // validity as a 0/1 FACTOR built from single compares (x * 1 = x, finite * 0 = 0): no select on a lane mask
+            // that the scalar ALU has just combined (see corners_setup in tt_device.h)
+            const float vf = (ray_ok ? 1.f : 0.f) * (si < s_end ? 1.f : 0.f);
+            const float sbar = in.up[0] * vf, gbx = in.up[1] * vf, gby = in.up[2] * vf, gbz = in.up[3] * vf;
             TT_PHASE(0);
             if (!__any(sbar != 0.f || gbx != 0.f || gby != 0.f || gbz != 0.f)) continue;  // exact
             float tm, px, py, pz;
@@ -650,13 +652,14 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         in_next = load_step(sb0 + tg.sb);
         const int si = sb0 + ks;
         const bool valid = ray_ok && si < s_end;
+        const float vf = (ray_ok ? 1.f : 0.f) * (si < s_end ? 1.f : 0.f);
         // ---- upstream: cbar_o = shrink * w_i * g_rgb[ray,o] * 1.002 * s(1-s) + g_features ----
         float cb[3];
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             const float s = sigmoid_(in.f[o]);
             const float c = shrink * in.wgt * grgb[o] * 1.002f * s * (1.f - s) + in.gf[o];
-            cb[o] = valid ? c : 0.f;
+            cb[o] = c * vf;  // 0/1 factor, not a select on a freshly combined lane mask (see k_decode_bwd_geo)
         }
         TT_PHASE(0);
         if (!__any(cb[0] != 0.f || cb[1] != 0.f || cb[2] != 0.f)) continue;  // exact: nothing flows back
