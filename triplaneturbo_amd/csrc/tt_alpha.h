@@ -5,7 +5,7 @@
 
 struct AlphaTerms {
     float alpha, rat, den, sA, sB, half, dic_dcos;
-    bool pass;
+    float pass;
 };
 
 __device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }  // 1 ulp
@@ -27,7 +27,8 @@ __device__ __forceinline__ AlphaTerms neus_alpha_terms(float sdf, float cosv, fl
     a.den = a.sA + 1e-5f;
     a.rat = ((a.sA - a.sB) + 1e-5f) * rcp_(a.den);
     a.alpha = fminf(fmaxf(a.rat, 0.f), 1.f);
-    a.pass = a.rat >= 0.f && a.rat <= 1.f;
+    // 1 inside the clip, 0 outside -- a FACTOR made of single compares, not a combined lane mask (tt_device.h, corners_setup)
+    a.pass = (a.rat >= 0.f ? 1.f : 0.f) * (a.rat <= 1.f ? 1.f : 0.f);
     return a;
 }
 

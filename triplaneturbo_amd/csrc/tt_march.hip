@@ -302,7 +302,7 @@ __device__ __forceinline__ f32x4 march_pass_bwd(const MarchBwdParams& p, const B
     // (lanes hold the samples of a pass in REVERSE order: the sample after this one sits in lane - 1)
     const float Rnext = wave_affine_prev(1.f - alpha, V * alpha, Rcarry);
     const float dalpha = Ti * (V - Rnext);
-    const float drat = (valid && a.pass) ? dalpha : 0.f;
+    const float drat = dalpha * a.pass * (valid ? 1.f : 0.f);
     const float iden = rcp_(a.den);
     const float dnum = drat * iden, dden = -drat * a.rat * iden;
     const float dA = (dnum + dden) * a.sA * (1.f - a.sA) * kstd, dB = (-dnum) * a.sB * (1.f - a.sB) * kstd;

@@ -89,12 +89,13 @@ __global__ __launch_bounds__(256, 1) void k_points_bwd_x(PointsBwdXParams p) {
         const float* pbase = p.packed + (size_t)(b / p.views_per_prompt) * plane_stride;
         const float px = p.points[idx * 3 + 0], py = p.points[idx * 3 + 1], pz = p.points[idx * 3 + 2];
         const float X = scale_coord(px, p.radius), Y = scale_coord(py, p.radius), Z = scale_coord(pz, p.radius);
-        const float gs = (valid && p.g_sdf) ? p.g_sdf[idx] : 0.f;
+        const float vf = valid ? 1.f : 0.f;  // (idx is a valid address for every lane; validity as a factor)
+        const float gs = p.g_sdf ? p.g_sdf[idx] * vf : 0.f;
         float gg[3], gf[3];
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
-            gg[o] = (valid && p.g_sdf_grad) ? p.g_sdf_grad[idx * 3 + o] : 0.f;
-            gf[o] = (valid && p.g_feat) ? p.g_feat[idx * 3 + o] : 0.f;
+            gg[o] = p.g_sdf_grad ? p.g_sdf_grad[idx * 3 + o] * vf : 0.f;
+            gf[o] = p.g_feat ? p.g_feat[idx * 3 + o] * vf : 0.f;
         }
         const bool need_geo = __any(gs != 0.f || gg[0] != 0.f || gg[1] != 0.f || gg[2] != 0.f);
         const bool need_tex = __any(gf[0] != 0.f || gf[1] != 0.f || gf[2] != 0.f);
