@@ -769,6 +769,8 @@ struct TileGeom {
 
 // ray handled by lane j (0..31) of ray block b; the lane's sample offset inside a tile step is j % sb
 __device__ __forceinline__ long long tile_ray(const TileGeom& g, long long b, int j, bool& rvalid) {
+    // The returned index is ALWAYS a valid ray (clamped arithmetically, not selected on the validity mask): a lane
+    // outside the image / past the last ray works on a duplicate whose contributions `rvalid` switches off.
     long long ray;
     const int jr = j / g.sb;
     if (g.image_w > 0) {
@@ -777,13 +779,13 @@ __device__ __forceinline__ long long tile_ray(const TileGeom& g, long long b, in
         const int by = rem / g.bpr, bx = rem - by * g.bpr;
         const int x = bx * g.bw + (jr % g.bw), y = by * g.bh + (jr / g.bw);
         rvalid = x < g.image_w && y < g.image_h;
-        ray = view * g.rays_per_view + (long long)y * g.image_w + x;
+        ray = view * g.rays_per_view + (long long)min(y, g.image_h - 1) * g.image_w + min(x, g.image_w - 1);
     } else {
         ray = b * (32 / g.sb) + jr;
         rvalid = true;
     }
     rvalid = rvalid && ray < g.n_rays;
-    return rvalid ? ray : g.n_rays - 1;
+    return ray < g.n_rays - 1 ? ray : g.n_rays - 1;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
