@@ -197,9 +197,9 @@ struct Corners {
 // compiles to v_cmp -> s_and_b64 (SALU combination of lane masks) -> v_cndmask, and on MI355X that sequence was
 // observed to deliver STALE mask bits for lanes 48..63 to the first select when the SIMD runs a single wave (tail of a
 // kernel): w[2] of the upper half-wave wrong in ~5 of 9375 tiles per launch, nondeterministically, while the offset
-// selected by the same mask two instructions later was right (tools/stress_export.py; gone with s_nop between mask and
-// select, and with -mllvm -amdgpu-waitcnt-forcezero; isolated sequences in tools/sgpr_hazard_probe.hip do not
-// reproduce it).  Here every flag is a float 0/1 made by ONE compare + select (VALU -> VALU through VCC, a hazard hipcc
+// selected by the same mask two instructions later was right (tools/stress_export.py; gone with
+// -mllvm -amdgpu-waitcnt-forcezero and whenever the masks are re-materialised by VALU compares before the selects, with
+// or without s_nops; isolated sequences in tools/sgpr_hazard_probe.hip do not reproduce it).  Here every flag is a float 0/1 made by ONE compare + select (VALU -> VALU through VCC, a hazard hipcc
 // handles) and combined by multiplication; results are bit-identical to the textbook form (x * 1 = x, finite * 0 = 0).
 __device__ __forceinline__ void corners_setup(float gx, float gy, int H, int W, bool valid, Corners& c) {
     // same op order as the reference: ((coord + 1) * size - 1) / 2
