@@ -129,10 +129,23 @@ __device__ __forceinline__ void flush_wgrad(const f32x16 (&acc)[NX / 32][NY / 32
 // occupied slot is flushed with ONE atomic instruction per half-wave straight from the accumulator registers.
 #define MS XS  // row stride of M (floats): same conflict-free stride as the transposition scratch
 
+// M region: either the fp32 matrix (65 rows x MS floats, EXACT) or its split-fp16 image -- two planes (hi, lo) of
+// 65 rows x M16_RS halves (32 samples + pad: 80-byte rows keep the 16-byte A-operand reads spread over the banks)
+#define M16_RS 40
+#define M16_PLANE (65 * M16_RS)
+#define SCATTER_M_FLOATS 2624 /* >= max(65 * MS, 2 * M16_PLANE / 2), multiple of 64 */
+template <bool EXACT>
 __device__ __forceinline__ void scatter_clear(float* M, int lane) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (EXACT) {  // 64 rows of the fp32 matrix (the dump row is never read)
 #pragma unroll
-    for (int g = 0; g < MS / 4; ++g) *reinterpret_cast<f32x4*>(M + lane * MS + 4 * g) = z;
+        for (int g = 0; g < MS / 4; ++g) *reinterpret_cast<f32x4*>(M + lane * MS + 4 * g) = z;
+    } else {
+#pragma unroll
+        for (int g = 0; g < SCATTER_M_FLOATS / 256; ++g) *reinterpret_cast<f32x4*>(M + (g * 64 + lane) * 4) = z;
+        if (lane < (SCATTER_M_FLOATS % 256) / 4)
+            *reinterpret_cast<f32x4*>(M + ((SCATTER_M_FLOATS / 256) * 64 + lane) * 4) = z;
+    }
 }
 
 // The three planes of one tile step, software-pipelined.  Everything except the rare lost-reference path is
@@ -144,18 +157,32 @@ __device__ __forceinline__ void scatter_clear(float* M, int lane) {
 // Tags are double-buffered (the flush of plane p reads them after plane p+1 claimed its slots).
 // LDS per wave: M = 64 rows + 1 dump row (stride MS), tags = 2 x 64 slots + 32 dummies (SCATTER_TAG_INTS).
 #define SCATTER_TAG_INTS 160
-#define SCATTER_M_ROWS 65
 
 struct PlaneRefs {  // the two corners (2hi, 2hi+1) of this lane's sample in one plane
-    float c0, c1;   // coefficient (0: no reference)
+    float c0, c1;   // coefficient (0: no reference), normalised per sample unless EXACT
     int o0, o1;     // absolute texel index (prompt and plane included)
     int h0, h1;     // slot: 8x8 torus hash of the texel coordinates
+    float qs;       // factor the sample's row of Q must be staged with (inverse of the coefficient normalisation)
 };
+// NORM: the sample's four coefficients are scaled by the power of two that brings the largest into [2^14, 2^15) -- the
+// top of the fp16 range, as tt_mfma16.h does for every split operand -- and the sample's row of Q by its inverse:
+// M Q is unchanged (exactly), column j of M and row j of Q belong to the same sample.
+template <bool NORM>
 __device__ __forceinline__ PlaneRefs plane_refs(const float (&coef)[4], const int (&aoff)[4], const int (&hs)[4],
                                                 int hi) {
     PlaneRefs r;
-    r.c0 = hi ? coef[2] : coef[0];
-    r.c1 = hi ? coef[3] : coef[1];
+    float cn = 1.f;
+    r.qs = 1.f;
+    if (NORM) {
+        const float m = fmaxf(fmaxf(__builtin_fabsf(coef[0]), __builtin_fabsf(coef[1])),
+                              fmaxf(__builtin_fabsf(coef[2]), __builtin_fabsf(coef[3])));
+        int E = (int)(__builtin_bit_cast(unsigned, m) >> 23);
+        E = E < 16 ? 16 : (E > 240 ? 240 : E);
+        cn = __builtin_bit_cast(float, (unsigned)(268 - E) << 23);    // 2^(141 - E)
+        r.qs = __builtin_bit_cast(float, (unsigned)(E - 14) << 23);   // 1 / cn
+    }
+    r.c0 = (hi ? coef[2] : coef[0]) * cn;
+    r.c1 = (hi ? coef[3] : coef[1]) * cn;
     r.o0 = hi ? aoff[2] : aoff[0];
     r.o1 = hi ? aoff[3] : aoff[1];
     r.h0 = hi ? hs[2] : hs[0];
@@ -177,6 +204,31 @@ __device__ __forceinline__ void scatter_init_tags(int* tags, int lane) {
 #ifdef TT_TUNING
 __device__ unsigned long long g_scatter_stats[4];  // [0] active references, [1] lost references, [2] plane-tiles
 #endif
+// store / clear one coefficient of M (column i = this lane's sample; row 64 = dump row)
+template <bool EXACT>
+__device__ __forceinline__ void m_store(float* M, int row, int i, float c) {
+    if (EXACT) {
+        M[row * MS + i] = c;
+    } else {
+        half_t h, l;
+        split16(c, h, l);
+        half_t* Mh = reinterpret_cast<half_t*>(M);
+        Mh[row * M16_RS + i] = h;
+        Mh[M16_PLANE + row * M16_RS + i] = l;
+    }
+}
+template <bool EXACT>
+__device__ __forceinline__ void m_zero(float* M, int row, int i) {
+    if (EXACT) {
+        M[row * MS + i] = 0.f;
+    } else {
+        half_t* Mh = reinterpret_cast<half_t*>(M);
+        Mh[row * M16_RS + i] = (half_t)0.f;
+        Mh[M16_PLANE + row * M16_RS + i] = (half_t)0.f;
+    }
+}
+
+template <bool EXACT>
 __device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M, int* tg, int* dummy, int i) {
     ClaimState s;
     const bool a0 = r.c0 != 0.f, a1 = r.c1 != 0.f;
@@ -188,8 +240,8 @@ __device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M
     s.w1 = s.m1 || old1 == r.o1;
     s.l0 = a0 && !s.w0;
     s.l1 = a1 && !s.w1;
-    M[(s.w0 ? r.h0 : 64) * MS + i] = r.c0;
-    M[(s.w1 ? r.h1 : 64) * MS + i] = r.c1;
+    m_store<EXACT>(M, s.w0 ? r.h0 : 64, i, r.c0);
+    m_store<EXACT>(M, s.w1 ? r.h1 : 64, i, r.c1);
 #ifdef TT_TUNING
     {
         const int na = __popcll(__ballot(a0)) + __popcll(__ballot(a1));
@@ -243,7 +295,13 @@ __device__ __forceinline__ void scatter_lost(const PlaneRefs& r, const ClaimStat
 
 // prep(pl, refs): corner set-up of plane pl for this lane's sample (and, where Q differs per plane, its staging into
 // Qs[j*33 + ch] -- the previous plane's B operand is in registers by then).  M: all-zero on entry and on exit.
-template <class Prep>
+// G = M Q for the two 32-slot tiles is either 32 fp32 MFMAs (EXACT, and the texture kernel -- see there; 2048
+// matrix-pipe cycles) or, in the geometry kernel (3.51 -> 3.33 ms), the split-fp16 scheme of tt_mfma16.h: M is already a
+// (hi, lo) fp16 image normalised per sample (plane_refs<true>, m_store), the B operand (16 samples of this lane's
+// channel per half-wave) is normalised per channel and split, and 12 fp16 MFMAs (384 cycles) do the work.
+// prep(pl, refs): corner set-up of plane pl for this lane's sample AND the staging of its row of Q, scaled by refs.qs,
+// into Qs[j*33 + ch] (the previous plane's B operand is in registers by then).  M: all-zero on entry and on exit.
+template <bool EXACT, class Prep>
 __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigned grad_bytes, const float* Qs, float* M,
                                                int* tags, float* Ls, int i, int hi, Prep&& prep) {
     // BUFFER atomics with a 32-bit BYTE offset (texel << 7 | channel * 4) from the gradient copy: an empty slot's tag
@@ -256,33 +314,92 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
     PlaneRefs rc, rn;
     ClaimState sc, sn;
     prep(0, rc);
-    sc = scatter_claim(rc, M, tags, dummy, i);
+    sc = scatter_claim<EXACT>(rc, M, tags, dummy, i);
     scatter_lost(rc, sc, Qs, Ls, grsrc, i, hi);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
         int* const tg = tags + 64 * (pl & 1);
-        // ---- operands of G = M Q into registers; M back to all-zero ----
-        f32x4 a4[2][4];
-        float bq[16];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4)
-                a4[m][t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) bq[t] = Qs[(t + 16 * hi) * 33 + i];
-        M[(sc.w0 ? rc.h0 : 64) * MS + i] = 0.f;
-        M[(sc.w1 ? rc.h1 : 64) * MS + i] = 0.f;
-        if (pl < 2) prep(pl + 1, rn);
-        // ---- the two 32-slot tiles advance as independent accumulator chains; the next plane's claims fill the
-        // matrix-pipe time ----
+        // ---- G = M Q; once its operands are in registers: M back to all-zero, next plane's set-up and Q row; the
+        // next plane's claims fill the matrix-pipe time ----
         f32x16 acc0 = ZERO16, acc1 = ZERO16;
+        if (EXACT) {
+            f32x4 a4[2][4];
+            float bq[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0][t >> 2][t & 3], bq[t], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1][t >> 2][t & 3], bq[t], acc1, 0, 0, 0);
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4)
+                    a4[m][t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) bq[t] = Qs[(t + 16 * hi) * 33 + i];
+            M[(sc.w0 ? rc.h0 : 64) * MS + i] = 0.f;
+            M[(sc.w1 ? rc.h1 : 64) * MS + i] = 0.f;
+            if (pl < 2) prep(pl + 1, rn);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0][t >> 2][t & 3], bq[t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1][t >> 2][t & 3], bq[t], acc1, 0, 0, 0);
+            }
+        } else {
+            const half_t* Mh = reinterpret_cast<const half_t*>(M);
+            h8_t ah[2][2], al[2][2];  // [slot tile][k-step]: 8 samples 16 ks + 8 hi .. + 7 of slot row 32 m + i
+            float bs[2][8];           // the same samples of channel i
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const half_t* a = Mh + (32 * m + i) * M16_RS + 16 * ks + 8 * hi;
+                    ah[m][ks] = *reinterpret_cast<const h8_t*>(a);
+                    al[m][ks] = *reinterpret_cast<const h8_t*>(a + M16_PLANE);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bs[ks][j] = Qs[(16 * ks + 8 * hi + j) * 33 + i];
+            m_zero<false>(M, sc.w0 ? rc.h0 : 64, i);
+            m_zero<false>(M, sc.w1 ? rc.h1 : 64, i);
+            if (pl < 2) prep(pl + 1, rn);
+            // per-channel normalisation of the B operand to the top of the fp16 range (column = this lane and lane ^ 32)
+            float mx = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx = fmaxf(mx, __builtin_fabsf(bs[ks][j]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            int E = (int)(__builtin_bit_cast(unsigned, mx) >> 23);
+            E = E < 16 ? 16 : (E > 240 ? 240 : E);
+            const float bsc = __builtin_bit_cast(float, (unsigned)(268 - E) << 23);
+            const float bun = __builtin_bit_cast(float, (unsigned)(E - 14) << 23);
+            h8_t bh[2], bl[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = bs[ks][2 * j] * bsc, x1 = bs[ks][2 * j + 1] * bsc;
+                    const h2_t ph = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+                    const h2_t pq =
+                        __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0 - (float)ph.x, x1 - (float)ph.y));
+                    bh[ks][2 * j] = ph.x;
+                    bh[ks][2 * j + 1] = ph.y;
+                    bl[ks][2 * j] = pq.x;
+                    bl[ks][2 * j + 1] = pq.y;
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][ks], bh[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][ks], bh[ks], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][ks], bl[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][ks], bl[ks], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][ks], bh[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][ks], bh[ks], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0[r] *= bun;
+                acc1[r] *= bun;
+            }
         }
-        if (pl < 2) sn = scatter_claim(rn, M, tags + 64 * ((pl + 1) & 1), dummy, i);
+        if (pl < 2) sn = scatter_claim<EXACT>(rn, M, tags + 64 * ((pl + 1) & 1), dummy, i);
         // ---- flush: one 128-byte atomic per slot pair, straight from the accumulators (slot of reg 4g+e = LIDX) ----
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -494,20 +611,21 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 TT_PHASE(5);
                 // ---- scatter d/d geometry planes: texel(p,c)[ch] += q[ch] * coef(p,c) ----
                 if (region && !TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
-                    scatter_clear(Xs, lane);  // M = 0 (Xs held wgrad staging); row 64 (= first row of Ys): dump row
-                    float* Qs = Ys + XS;      // q staged as [sample][32], stride 33 (same for the 3 planes)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) Qs[i * 33 + LIDX(r, hi)] = q[r];
+                    scatter_clear<EXACT>(Xs, lane);  // M = 0 (Xs held wgrad staging; SCATTER_M_FLOATS reach into Ys)
+                    float* Qs = Xs + SCATTER_M_FLOATS;  // the sample's row of Q: q scaled per plane, stride 33
                     TT_PHASE(9);
                     const int tex0 = (int)(pofs / TT_C);
-                    scatter_planes(grad_out, grad_bytes, Qs, Xs, tags, Qs + 32 * 33, i, hi, [&](int pl, PlaneRefs& refs) {
+                    scatter_planes<EXACT>(grad_out, grad_bytes, Qs, Xs, tags, Qs + 32 * 33, i, hi,
+                                          [&](int pl, PlaneRefs& refs) {
                         Corners c;
                         float coef[4];  // per corner: w sbar + dw/dx . gbar -- gather AND scatter coefficient
                         geo_corner_coefs(pl, H, W, X, Y, Z, rvalid, sbar, gbx, gby, gbz, ju, jv, c, coef);
                         int aoff[4];
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) aoff[q4] = tex0 + (int)(pl * HW) + c.off[q4];
-                        refs = plane_refs(coef, aoff, c.hs, hi);
+                        refs = plane_refs<!EXACT>(coef, aoff, c.hs, hi);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Qs[i * 33 + LIDX(r, hi)] = q[r] * refs.qs;
                     });
                     TT_PHASE(10);
                 }
@@ -761,24 +879,25 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         }
         // ---- ebar = V1^T k1bar (one plane at a time) ; scatter texel(3+p, c)[ch] += w_c * ebar[32p + ch] ----
         if (region && !TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
-            float* M = Xs;              // rows 0..63: the slot x sample coefficient matrix, row 64: dump row
-            float* Es = Xs + SCATTER_M_ROWS * XS;  // ebar staged as [sample][32], stride 33, then the fallback lists
-            scatter_clear(M, lane);
+            float* M = Xs;              // rows 0..63: the slot x sample coefficient matrix (fp32), row 64: dump row
+            float* Es = Xs + 65 * XS;   // ebar rows staged as [sample][32], stride 33, then the fallback lists
+            scatter_clear<true>(M, lane);
             // ebar = V1^T k1bar for the three planes in ONE product (96 rows: k1bar is split into fp16 terms once)
             float eb[48];
             mvtx<EXACT, 96, 64, V1S>(Lt + TV1T, Lt + TV1, kb1, eb, i, hi);
             TT_PHASE(9);
             const int tex0 = (int)(pofs / TT_C);
-            scatter_planes(grad_out, grad_bytes, Es, M, tags, Es + 32 * 33, i, hi, [&](int pl, PlaneRefs& refs) {
+            // (fp32 combine GEMM here: the split-fp16 one costs this kernel 26 more spilled registers, 3.88 -> 4.16 ms)
+            scatter_planes<true>(grad_out, grad_bytes, Es, M, tags, Es + 32 * 33, i, hi, [&](int pl, PlaneRefs& refs) {
                 Corners c;
                 corners_setup(PLANE_U(pl, X, Y, Z), PLANE_V(pl, X, Y, Z), H, W, valid, c);
                 int aoff[4];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4)  // absolute texel index, prompt included
                     aoff[q4] = tex0 + (int)((3 + pl) * HW) + c.off[q4];
+                refs = plane_refs<false>(c.w, aoff, c.hs, hi);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[16 * pl + r];
-                refs = plane_refs(c.w, aoff, c.hs, hi);
             });
             TT_PHASE(10);
         }
