@@ -76,9 +76,12 @@ geo_names = ["upstream (d sdf, d sdf_grad) + skip test", "gather f, u (12 corner
              "  scatter: flush (predicated 128-byte atomics)", "  scatter: restore M / tags",
              "  scatter: lost-reference fallback", "", "", ""]
 print(f"texture backward: {buf[12] / n / 1024:.0f} live tile steps per wave per launch, {buf[13] / max(buf[12], 1):.1f} of 32 lanes live on average, {buf[14] / max(buf[12], 1):.1f} with |cbar| > 1e-12")
-print(f"scatter (both kernels): {buf[39] / n:.0f} plane-tiles per step, {buf[37] / max(buf[39], 1):.1f} active references per plane-tile, "
-      f"{100.0 * buf[38] / max(buf[37], 1):.1f} % of them lost their slot (direct path)")
-buf[12] = buf[13] = buf[14] = buf[37] = buf[38] = buf[39] = 0
+tex_pt, geo_pt = 3 * buf[12], buf[36]
+print(f"scatter, texture kernel: {buf[15] / max(tex_pt, 1):.1f} active references per plane-tile, "
+      f"{100.0 * buf[16] / max(buf[15], 1):.1f} % of them lost their slot (direct path)")
+print(f"scatter, geometry kernel: {buf[34] / max(geo_pt, 1):.1f} active references per plane-tile, "
+      f"{100.0 * buf[35] / max(buf[34], 1):.1f} % of them lost their slot (direct path)")
+buf[12] = buf[13] = buf[14] = buf[15] = buf[16] = buf[34] = buf[35] = buf[36] = 0
 for title, ofs, nms in (("k_decode_bwd_tex", 0, names), ("k_decode_bwd_geo", 20, geo_names)):
     tot = sum(buf[ofs:ofs + 20])
     print(f"== {title}: {tot / n / 1024 / 1e6:.2f} M shader cycles per wave ==")

@@ -201,9 +201,6 @@ __device__ __forceinline__ void scatter_init_tags(int* tags, int lane) {
     if (lane < 32) tags[128 + lane] = -2;  // dummies: never empty, never equal to a texel index
 }
 
-#ifdef TT_TUNING
-__device__ unsigned long long g_scatter_stats[4];  // [0] active references, [1] lost references, [2] plane-tiles
-#endif
 // store / clear one coefficient of M (column i = this lane's sample; row 64 = dump row)
 template <bool EXACT>
 __device__ __forceinline__ void m_store(float* M, int row, int i, float c) {
@@ -228,8 +225,10 @@ __device__ __forceinline__ void m_zero(float* M, int row, int i) {
     }
 }
 
+// st (tuning build): per-wave counters [0] active references, [1] lost references, [2] plane-tiles
 template <bool EXACT>
-__device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M, int* tg, int* dummy, int i) {
+__device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M, int* tg, int* dummy, int i,
+                                                    unsigned long long* st = nullptr) {
     ClaimState s;
     const bool a0 = r.c0 != 0.f, a1 = r.c1 != 0.f;
     const int old0 = atomicCAS(a0 ? tg + r.h0 : dummy, -1, r.o0);
@@ -243,14 +242,10 @@ __device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M
     m_store<EXACT>(M, s.w0 ? r.h0 : 64, i, r.c0);
     m_store<EXACT>(M, s.w1 ? r.h1 : 64, i, r.c1);
 #ifdef TT_TUNING
-    {
-        const int na = __popcll(__ballot(a0)) + __popcll(__ballot(a1));
-        const int nl = __popcll(__ballot(s.l0)) + __popcll(__ballot(s.l1));
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&g_scatter_stats[0], (unsigned long long)na);
-            atomicAdd(&g_scatter_stats[1], (unsigned long long)nl);
-            atomicAdd(&g_scatter_stats[2], 1ull);
-        }
+    if (st) {  // wave-uniform values, flushed once per wave with the phase timers
+        st[0] += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
+        st[1] += __popcll(__ballot(s.l0)) + __popcll(__ballot(s.l1));
+        st[2] += 1;
     }
 #endif
     return s;
@@ -303,7 +298,8 @@ __device__ __forceinline__ void scatter_lost(const PlaneRefs& r, const ClaimStat
 // into Qs[j*33 + ch] (the previous plane's B operand is in registers by then).  M: all-zero on entry and on exit.
 template <bool EXACT, class Prep>
 __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigned grad_bytes, const float* Qs, float* M,
-                                               int* tags, float* Ls, int i, int hi, Prep&& prep) {
+                                               int* tags, float* Ls, int i, int hi, Prep&& prep,
+                                               unsigned long long* st = nullptr) {
     // BUFFER atomics with a 32-bit BYTE offset (texel << 7 | channel * 4) from the gradient copy: an empty slot's tag
     // is -1, its offset 0xFFFFFF80 + 4 ch lies beyond num_records (the host refuses gradient buffers of 4 GB - 256 B
     // and more) and the hardware range check drops the atomic -- no compare, no exec-mask branch per slot (the
@@ -314,7 +310,7 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
     PlaneRefs rc, rn;
     ClaimState sc, sn;
     prep(0, rc);
-    sc = scatter_claim<EXACT>(rc, M, tags, dummy, i);
+    sc = scatter_claim<EXACT>(rc, M, tags, dummy, i, st);
     scatter_lost(rc, sc, Qs, Ls, grsrc, i, hi);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
@@ -399,7 +395,7 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
                 acc1[r] *= bun;
             }
         }
-        if (pl < 2) sn = scatter_claim<EXACT>(rn, M, tags + 64 * ((pl + 1) & 1), dummy, i);
+        if (pl < 2) sn = scatter_claim<EXACT>(rn, M, tags + 64 * ((pl + 1) & 1), dummy, i, st);
         // ---- flush: one 128-byte atomic per slot pair, straight from the accumulators (slot of reg 4g+e = LIDX) ----
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -626,7 +622,11 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                         refs = plane_refs<!EXACT>(coef, aoff, c.hs, hi);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) Qs[i * 33 + LIDX(r, hi)] = q[r] * refs.qs;
-                    });
+                    }
+#ifdef TT_TUNING
+                    , ph_acc + 14
+#endif
+                    );
                     TT_PHASE(10);
                 }
             }
@@ -719,6 +719,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     float accV3[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // [half of the 64 indices][output]; this lane: 16 samples
 #ifdef TT_TUNING
     unsigned long long ph_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long scat_st[3] = {0, 0, 0};
     unsigned long long ph_t = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -898,13 +899,19 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
                 refs = plane_refs<false>(c.w, aoff, c.hs, hi);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[16 * pl + r];
-            });
+            }
+#ifdef TT_TUNING
+            , scat_st
+#endif
+            );
             TT_PHASE(10);
         }
       }
     }
 #ifdef TT_TUNING
     TT_PHASE(11);
+    ph_acc[15] = scat_st[0];  // active references
+    ph_acc[16] = scat_st[1];  // lost references (plane-tiles = 3 per live tile step, slot 12)
     if (p.phase_cycles && lane == 0)
         for (int k = 0; k < 20; ++k) atomicAdd(p.phase_cycles + k, ph_acc[k]);
 #endif
@@ -982,16 +989,6 @@ extern "C" int tt_tuning_phase_cycles(unsigned long long* out40) {
     if (hipDeviceSynchronize() != hipSuccess) return -4;
     if (out40 && hipMemcpy(out40, g_phase_cycles, 40 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
         return -4;
-    {  // scatter statistics ride in the three unused slots at the end
-        unsigned long long st[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
-        if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_scatter_stats), sizeof(st)) != hipSuccess) return -4;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_scatter_stats), zero, sizeof(zero)) != hipSuccess) return -4;
-        if (out40) {
-            out40[37] = st[0];
-            out40[38] = st[1];
-            out40[39] = st[2];
-        }
-    }
     return hipMemset(g_phase_cycles, 0, 40 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
 }
 #endif
