@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 10
+#define TT_ABI_VERSION 11
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -171,19 +171,33 @@ int tt_decode_rays(const float* packed, const tt_mlp_weights* w, const float* ra
                    const float* t_starts, const float* t_ends, const tt_render_cfg* cfg, int32_t flags, float* sdf,
                    float* sdf_grad, float* features, void* stream);
 
-/* Level-0 sample intervals: edges s_k = linspace(0,1,n+1)[k] (+ (jitter-0.5)/n on interior edges if jitter
- * (n_rays, n+1), U[0,1), is given), t = s*far + (1-s)*near; t_starts/t_ends (n_rays, n). */
+/* Where the n + 1 edges of a level are placed in cdf space (u in [0,1]) before going through the inverse cdf.  The
+ * reference draws both levels with nerfacc v0.5.2 `importance_sampling(intervals, cdfs, n, stratified)`
+ * (threestudio/models/estimators.py:72-90); nerfacc is un-vendored and its pdf.cu is not available here, so its exact
+ * convention is UNVERIFIABLE in this build and the choice is an explicit, switchable contract:
+ *   TT_PLACE_TT     (default) u_j = j / n, j = 0..n: first / last edge pinned to near / far.  Stratified: level-0
+ *                   interior edges -+ half a cell ((jitter - 0.5) / n), fine level u_j + jitter_j / n clamped to [0,1].
+ *   TT_PLACE_CENTER u_j = (j + 0.5) / (n + 1): the centres of n + 1 equal cells, nothing pinned to 0 or 1.
+ *                   Stratified: u_j = (j + jitter_j) / (n + 1), one uniform draw per cell.
+ * Under either one the empirical distribution of the resampled edges follows the proposal cdf within one cell
+ * (tests/test_gpu_sampler.py checks that against the cdf itself, not against a restatement of the kernel). */
+enum tt_sample_placement { TT_PLACE_TT = 0, TT_PLACE_CENTER = 1 };
+
+/* Level-0 sample intervals from the uniform cdf: edges s_k = u_k of `placement` (jitter (n_rays, n+1), U[0,1), or
+ * null = deterministic), t = s*far + (1-s)*near (_transform_stot "uniform", estimators.py:104-118);
+ * t_starts/t_ends (n_rays, n). */
 int tt_sample_uniform(int64_t n_rays, int32_t n_samples, float near_plane, float far_plane, const float* jitter,
-                      float* t_starts, float* t_ends, void* stream);
+                      int32_t placement, float* t_starts, float* t_ends, void* stream);
 
 /* Importance resampling of one proposal level.  In: proposal intervals t_starts/t_ends (n_rays, K) and the sdf
  * (n_rays, K) at their mid-points (tt_decode_rays, flags = 0).  sigma = NeuS alpha over a fixed step / step,
- * T = exp(-exclusive_cumsum(sigma dt)), cdf = 1 - [T, 0]; F + 1 fine edges at u_j = j/F (+ u_jitter/F, clamped, if
- * u_jitter (n_rays, F+1) is given) through the piecewise-linear inverse cdf; out = the K + F + 2 edges merged in
- * increasing order as out_t_starts/out_t_ends (n_rays, K + F + 1). */
+ * T = exp(-exclusive_cumsum(sigma dt)), cdf = 1 - [T, 0]; F + 1 fine edges at the u_j of `placement` (u_jitter
+ * (n_rays, F+1), U[0,1), or null = deterministic) through the piecewise-linear inverse cdf; out = the K + F + 2
+ * edges merged in increasing order as out_t_starts/out_t_ends (n_rays, K + F + 1). */
 int tt_sample_importance(const float* t_starts, const float* t_ends, const float* sdf, int64_t n_rays,
                          int32_t n_proposal, int32_t n_fine, float inv_std, float render_step_size,
-                         const float* u_jitter, float* out_t_starts, float* out_t_ends, void* stream);
+                         const float* u_jitter, int32_t placement, float* out_t_starts, float* out_t_ends,
+                         void* stream);
 
 /* Forward render for explicit sample intervals.
  * rays_o, rays_d (n_rays,3); t_starts, t_ends (n_rays,S).

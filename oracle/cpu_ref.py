@@ -461,26 +461,49 @@ def hypernet_background(dirs: Tensor, text_embed: Tensor, grid_params: Tensor, h
 # --------------------------------------------------------------------------
 # samplers
 # --------------------------------------------------------------------------
-def uniform_intervals(n_rays: int, n_samples: int, near: float, far: float, dtype=torch.float32):
-    """Level-0 of ImportanceEstimator.sampling with stratified=False
-    (threestudio/models/estimators.py:61-79, 104-118): n_samples equal
-    intervals on [near, far].  t_k = near + (far-near) * k / n_samples."""
-    s = torch.linspace(0.0, 1.0, n_samples + 1, dtype=dtype)
+def placement_u(n: int, placement: str = "tt", jitter: Optional[Tensor] = None, dtype=torch.float32,
+                level0: bool = False) -> Tensor:
+    """cdf-space positions u_j, j = 0..n, of the n + 1 edges of one sampling level (1, n+1) or, jittered, (R, n+1).
+    [parity unpinned: nerfacc v0.5.2's pdf.cu is unavailable, so the convention is an explicit contract, enum
+    tt_sample_placement in include/tt_abi.h]
+      "tt"     u_j = j / n; jitter: level 0 moves interior edges by (U - 0.5) / n, the fine level adds U / n, clamped
+      "center" u_j = (j + 0.5) / (n + 1); jitter: (j + U_j) / (n + 1)"""
+    j = torch.arange(n + 1, dtype=dtype)[None, :]
+    if placement == "center":
+        return (j + (0.5 if jitter is None else jitter.to(dtype))) / (n + 1)
+    if placement != "tt":
+        raise ValueError(placement)
+    u = torch.linspace(0.0, 1.0, n + 1, dtype=dtype)[None, :]
+    if jitter is None:
+        return u
+    if level0:
+        interior = ((j > 0) & (j < n)).to(dtype)
+        return u + interior * (jitter.to(dtype) - 0.5) / n
+    return (u + jitter.to(dtype) / n).clamp(0.0, 1.0)
+
+
+def uniform_intervals(n_rays: int, n_samples: int, near: float, far: float, dtype=torch.float32,
+                      placement: str = "tt", jitter: Optional[Tensor] = None):
+    """Level-0 of ImportanceEstimator.sampling (threestudio/models/estimators.py:61-79, 104-118): n_samples
+    intervals on [near, far] from the uniform cdf; with the default placement and no jitter
+    t_k = near + (far-near) * k / n_samples."""
+    s = placement_u(n_samples, placement, jitter, dtype, level0=True)
     t = s * far + (1 - s) * near  # _transform_stot "uniform"
-    t = t[None, :].expand(n_rays, -1)
+    t = t.expand(n_rays, -1)
     return t[:, :-1].contiguous(), t[:, 1:].contiguous()
 
 
-def importance_resample(t_edges: Tensor, cdfs: Tensor, n: int) -> Tensor:
-    """Deterministic (stratified=False) inverse-CDF placement of n+1 edges,
-    following nerfacc v0.5.2 pdf.importance_sampling semantics for a dense
-    batch: u_k = k/n (k=0..n) mapped through the piecewise-linear CDF.
+def importance_resample(t_edges: Tensor, cdfs: Tensor, n: int, placement: str = "tt",
+                        jitter: Optional[Tensor] = None) -> Tensor:
+    """Inverse-CDF placement of n+1 edges, following nerfacc v0.5.2
+    pdf.importance_sampling semantics for a dense batch: u_k (placement_u)
+    mapped through the piecewise-linear CDF.
     [parity unpinned: nerfacc's exact u convention lives in its pdf.cu]
 
     t_edges (R, K+1) increasing, cdfs (R, K+1) non-decreasing in [0,1].
     """
     R = t_edges.shape[0]
-    u = torch.linspace(0.0, 1.0, n + 1, dtype=t_edges.dtype)[None, :].expand(R, -1).contiguous()
+    u = placement_u(n, placement, jitter, t_edges.dtype).expand(R, -1).contiguous()
     idx = torch.searchsorted(cdfs.contiguous(), u, right=True)
     lo = (idx - 1).clamp(0, cdfs.shape[1] - 1)
     hi = idx.clamp(0, cdfs.shape[1] - 1)
@@ -493,15 +516,17 @@ def importance_resample(t_edges: Tensor, cdfs: Tensor, n: int) -> Tensor:
 
 
 def importance_sampling(sdf_fn, n_rays: int, n_prop: int, n_fine: int, near: float, far: float,
-                        inv_std: float, render_step_size: float, dtype=torch.float32):
-    """ImportanceEstimator.sampling, one proposal level, stratified=False
+                        inv_std: float, render_step_size: float, dtype=torch.float32, placement: str = "tt",
+                        jitter0: Optional[Tensor] = None, jitter1: Optional[Tensor] = None):
+    """ImportanceEstimator.sampling, one proposal level
     (threestudio/models/estimators.py:22-101; prop_sigma_fn =
-    generative_space_sdf_volume_renderer.py:243-299).
+    generative_space_sdf_volume_renderer.py:243-299).  jitter0 (n_rays, n_prop+1) / jitter1 (n_rays, n_fine+1):
+    the U[0,1) draws of the two levels (None = stratified=False).
 
     sdf_fn(t_starts, t_ends) -> sdf (n_rays, n_prop) evaluated at interval mid-points.
     Returns t_starts, t_ends (n_rays, n_prop + n_fine + 1).
     """
-    ts, te = uniform_intervals(n_rays, n_prop, near, far, dtype)
+    ts, te = uniform_intervals(n_rays, n_prop, near, far, dtype, placement, jitter0)
     t_vals = torch.cat([ts, te[:, -1:]], dim=1)
     sdf = sdf_fn(ts, te)
     sigma = proposal_density(sdf, inv_std, render_step_size)
@@ -510,7 +535,7 @@ def importance_sampling(sdf_fn, n_rays: int, n_prop: int, n_fine: int, near: flo
     excl = torch.cumsum(torch.cat([torch.zeros_like(sd[:, :1]), sd[:, :-1]], dim=1), dim=1)
     trans = torch.exp(-excl)
     cdfs = 1.0 - torch.cat([trans, torch.zeros_like(trans[:, :1])], dim=1)
-    t_fine = importance_resample(t_vals, cdfs, n_fine)
+    t_fine = importance_resample(t_vals, cdfs, n_fine, placement, jitter1)
     t_all, _ = torch.sort(torch.cat([t_vals, t_fine], dim=1), dim=1)
     return t_all[:, :-1].contiguous(), t_all[:, 1:].contiguous()
 

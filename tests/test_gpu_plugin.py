@@ -36,7 +36,7 @@ def _weights(g):
 def test_eval_render_matches_oracle_and_keys(dev):
     g, m, b, r, cfg = _build(dev)
     r.eval()
-    r.eval_termination_eps = 0.0  # parity: march every sample like the reference (tests/test_gpu_eval.py covers > 0)
+    assert r.eval_termination_eps == 0.0  # the DEFAULT marches every sample like the reference (opt-in: test_gpu_eval)
     gen = torch.Generator().manual_seed(1)
     P, n_view, Hh, Ww = 1, 2, 6, 8
     cache = torch.randn(P, 6, 32, 32, 32, generator=gen) * 0.5
@@ -305,3 +305,33 @@ def test_fused_composite_matches_torch_reference_ops(dev, mode):
                       mode, view_group=n_view)[0]
     gb, = torch.autograd.grad((o * outs_g[0].to(dev)).sum(), [bgc])
     torch.testing.assert_close(gb.cpu(), (outs_g[0] * (1 - op)).sum(0), rtol=1e-4, atol=1e-5)
+
+
+def test_composite_world_mode_without_c2w_and_broadcast_camera_distance(dev):
+    """normal_direction='world' needs no c2w (the reference only touches it for 'camera' / 'front', renderer :478-530)
+    and a 1-element camera_distances broadcasts over the views as it does in the reference's arithmetic (:452-456);
+    anything else that does not match the number of views is refused instead of being read out of bounds."""
+    from triplaneturbo_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, rpv = 3, 11
+    n = B * rpv
+    op, dep = torch.rand(n, 1, generator=g), torch.rand(n, 1, generator=g) * 3
+    fg, na, bg = torch.rand(n, 3, generator=g), torch.randn(n, 3, generator=g), torch.rand(3, generator=g)
+    cd1 = torch.tensor([1.7])
+    got = ops.composite(op.to(dev), dep.to(dev), fg.to(dev), na.to(dev), bg.to(dev), cd1.to(dev), None, rpv, "world")
+    want = ops.composite(op.to(dev), dep.to(dev), fg.to(dev), na.to(dev), bg.to(dev), cd1.expand(B).contiguous().to(dev),
+                         torch.eye(4).expand(B, 4, 4).contiguous().to(dev), rpv, "world")
+    for a, b in zip(got[:3], want[:3]):
+        assert torch.equal(a, b)
+    far, near = 1.7 + 3 ** 0.5, 1.7 - 3 ** 0.5
+    disp = torch.clamp((far - (dep * op + (1 - op) * far)) / (far - near), 0.0, 1.0)
+    torch.testing.assert_close(got[1].cpu(), disp, rtol=2e-5, atol=2e-6)
+    assert got[3] is None and got[4] is None
+    with pytest.raises(ValueError):
+        ops.composite(op.to(dev), dep.to(dev), fg.to(dev), na.to(dev), bg.to(dev), cd1.expand(2).contiguous().to(dev),
+                      None, rpv, "world")
+    with pytest.raises(ValueError):  # camera-space normals need the cameras
+        ops.composite(op.to(dev), dep.to(dev), fg.to(dev), na.to(dev), bg.to(dev), cd1.to(dev), None, rpv, "camera")
+    with pytest.raises(ValueError):
+        ops.composite(op.to(dev), dep.to(dev), fg.to(dev), na.to(dev), bg.to(dev), cd1.to(dev),
+                      torch.eye(4).expand(2, 4, 4).contiguous().to(dev), rpv, "camera")

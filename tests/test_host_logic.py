@@ -164,7 +164,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == 10
+    assert lib.tt_abi_version() == 11
     assert b"bad argument" in lib.tt_strerror(-1)
 
 
@@ -224,6 +224,9 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.tt_render_fwd(one, ctypes.byref(w), one, one, one, one, ctypes.byref(ok), *([null] + [one] * 10),
                              null) == -1  # passes the size check, then fails on the null output
     assert b"unsupported" in lib.tt_strerror(-2)
+    # sampler placement enum: only TT_PLACE_TT (0) / TT_PLACE_CENTER (1)
+    assert lib.tt_sample_uniform(4, 8, 0.1, 4.0, null, 2, one, one, null) == -1
+    assert lib.tt_sample_importance(one, one, one, 4, 8, 4, 100.0, 0.05, null, 7, one, one, null) == -1
 
 
 def test_product_library_never_reads_the_environment():

@@ -115,6 +115,7 @@ TT_R_EXACT_F32 = 2
 TT_Q_NORMAL = 1
 TT_Q_TEX = 2
 TT_Q_EXACT_F32 = 4
+PLACEMENTS = {"tt": 0, "center": 1}  # enum tt_sample_placement
 
 
 def load() -> ctypes.CDLL:
@@ -151,8 +152,8 @@ def load() -> ctypes.CDLL:
         "tt_hashgrid_n_params": [ctypes.POINTER(HashGridCfg)],
         "tt_hashgrid_fwd": [_P, _I64, _P, ctypes.POINTER(HashGridCfg), _P, _P],
         "tt_hashgrid_bwd": [_P, _I64, _P, ctypes.POINTER(HashGridCfg), _P, _P],
-        "tt_sample_uniform": [_I64, _I32, _F, _F, _P, _P, _P, _P],
-        "tt_sample_importance": [_P, _P, _P, _I64, _I32, _I32, _F, _F, _P, _P, _P, _P],
+        "tt_sample_uniform": [_I64, _I32, _F, _F, _P, _I32, _P, _P, _P],
+        "tt_sample_importance": [_P, _P, _P, _I64, _I32, _I32, _F, _F, _P, _I32, _P, _P, _P],
         "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
         "tt_grid_sample_2d_grad2_typed": [_I32] + [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
         "tt_debug_poison_queue": [_P],

@@ -23,16 +23,30 @@ __device__ __forceinline__ float linspace01(int k, int n) {
     return (k < (n + 1) / 2) ? step * (float)k : 1.f - step * (float)(n - k);
 }
 
+// u of edge j of n + 1 under the two placement conventions (tt_abi.h, tt_sample_placement):
+//   TT     : u_j = j / n, end points pinned (jitter handled by the callers: interior edges -+ half a cell at level 0,
+//            + U / n clamped at the fine level)
+//   CENTER : u_j = (j + 0.5) / (n + 1), or (j + U_j) / (n + 1) when jittered: n + 1 equal cells of [0,1], one edge per
+//            cell, nothing pinned to 0 or 1
+__device__ __forceinline__ float center_u(int j, int n, const float* jit) {
+    return ((float)j + (jit ? *jit : 0.5f)) / (float)(n + 1);
+}
+
 __global__ __launch_bounds__(256) void k_sample_uniform(long long n_rays, int n, float near, float far,
-                                                        const float* __restrict__ jitter, float* __restrict__ ts,
-                                                        float* __restrict__ te) {
+                                                        const float* __restrict__ jitter, int placement,
+                                                        float* __restrict__ ts, float* __restrict__ te) {
     const long long total = n_rays * (long long)(n + 1);
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const long long ray = idx / (n + 1);
         const int k = (int)(idx - ray * (n + 1));
-        float s = linspace01(k, n);
-        if (jitter && k > 0 && k < n) s = s + (jitter[idx] - 0.5f) / (float)n;  // interior edges only
+        float s;
+        if (placement == TT_PLACE_CENTER) {
+            s = center_u(k, n, jitter ? jitter + idx : nullptr);
+        } else {
+            s = linspace01(k, n);
+            if (jitter && k > 0 && k < n) s = s + (jitter[idx] - 0.5f) / (float)n;  // interior edges only
+        }
         const float t = s * far + (1.f - s) * near;
         if (k < n) ts[ray * n + k] = t;
         if (k > 0) te[ray * n + k - 1] = t;
@@ -46,6 +60,7 @@ struct ImportanceParams {
     const float* u;    // (n_rays, F + 1) U[0,1) or null (deterministic u_j = j / F)
     long long n_rays;
     int K, F;
+    int placement;
     float inv_std, step;
     float* out_ts;  // (n_rays, K + F + 1)
     float* out_te;
@@ -93,8 +108,13 @@ __global__ __launch_bounds__(256) void k_sample_importance(ImportanceParams p) {
 
     // ---- fine edges: inverse CDF at u_j ----
     for (int j = lane; j <= F; j += 64) {
-        float u = linspace01(j, F);
-        if (p.u) u = fminf(fmaxf(u + p.u[ray * (F + 1) + j] / (float)F, 0.f), 1.f);
+        float u;
+        if (p.placement == TT_PLACE_CENTER) {
+            u = center_u(j, F, p.u ? p.u + ray * (F + 1) + j : nullptr);
+        } else {
+            u = linspace01(j, F);
+            if (p.u) u = fminf(fmaxf(u + p.u[ray * (F + 1) + j] / (float)F, 0.f), 1.f);
+        }
         int lo = 0, hi = K + 1;  // searchsorted(cdf, u, right=True): first index with cdf > u
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -146,21 +166,25 @@ __global__ __launch_bounds__(256) void k_sample_importance(ImportanceParams p) {
 }
 
 extern "C" int tt_sample_uniform(int64_t n_rays, int32_t n_samples, float near_plane, float far_plane,
-                                 const float* jitter, float* t_starts, float* t_ends, void* stream) {
+                                 const float* jitter, int32_t placement, float* t_starts, float* t_ends,
+                                 void* stream) {
     if (n_rays <= 0 || n_samples <= 0 || !t_starts || !t_ends || !(far_plane > near_plane)) return TT_ERR_BAD_ARG;
+    if (placement != TT_PLACE_TT && placement != TT_PLACE_CENTER) return TT_ERR_BAD_ARG;
     const long long total = n_rays * (long long)(n_samples + 1);
     long long blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(k_sample_uniform, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long long)n_rays,
-                       n_samples, near_plane, far_plane, jitter, t_starts, t_ends);
+                       n_samples, near_plane, far_plane, jitter, (int)placement, t_starts, t_ends);
     return tt_check_launch();
 }
 
 extern "C" int tt_sample_importance(const float* t_starts, const float* t_ends, const float* sdf, int64_t n_rays,
                                     int32_t n_proposal, int32_t n_fine, float inv_std, float render_step_size,
-                                    const float* u_jitter, float* out_t_starts, float* out_t_ends, void* stream) {
+                                    const float* u_jitter, int32_t placement, float* out_t_starts,
+                                    float* out_t_ends, void* stream) {
     if (!t_starts || !t_ends || !sdf || !out_t_starts || !out_t_ends || n_rays <= 0 || n_proposal <= 0 || n_fine <= 0)
         return TT_ERR_BAD_ARG;
+    if (placement != TT_PLACE_TT && placement != TT_PLACE_CENTER) return TT_ERR_BAD_ARG;
     if (!(inv_std > 0.f) || !(render_step_size > 0.f)) return TT_ERR_BAD_ARG;
     const size_t lds = 4u * (2u * (n_proposal + 1) + (n_fine + 1)) * sizeof(float);
     if (lds > 64u * 1024u) return TT_ERR_UNSUPPORTED;
@@ -173,6 +197,7 @@ extern "C" int tt_sample_importance(const float* t_starts, const float* t_ends, 
     p.n_rays = n_rays;
     p.K = n_proposal;
     p.F = n_fine;
+    p.placement = placement;
     p.inv_std = inv_std;
     p.step = render_step_size;
     p.out_ts = out_t_starts;

@@ -111,9 +111,8 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
         comp_rgb_bg = bg[None, :].expand(n_rays, -1) if bg.ndim == 1 else bg
     n_prompts = packed.shape[0] if packed is not None else space_cache.shape[0]
     # one HIP kernel each way (tt_composite_fwd / _bwd)
-    comp = ops.composite(opacity, depth, comp_rgb_fg, r["normal_acc"], bg.contiguous(),
-                         camera_distances.reshape(-1).contiguous().float(), c2w.contiguous().float(), Hh * Ww,
-                         normal_direction, view_group=B // n_prompts)
+    comp = ops.composite(opacity, depth, comp_rgb_fg, r["normal_acc"], bg.contiguous(), camera_distances, c2w,
+                         Hh * Ww, normal_direction, view_group=B // n_prompts)
     comp_rgb, disparity, comp_normal, vis, vis_white = comp
     out = LazyOutputs({
         "comp_rgb": comp_rgb.view(B, Hh, Ww, -1),

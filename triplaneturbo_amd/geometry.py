@@ -80,6 +80,9 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
         if c.isosurface_deformable_grid:
             self.deformation_network = VanillaMLP(32, 3, c.mlp_network_config)
         self.register_buffer("bbox", torch.as_tensor([[-c.radius] * 3, [c.radius] * 3], dtype=torch.float32))
+        # TT_Q_EXACT_F32 for every per-point query of this module (forward and backward kernels): all matrix products
+        # on the fp32-input MFMA instead of split-fp16.  Not a reference knob, so not in Config.
+        self.exact_f32 = False
 
     # ---- generator half: delegated (stock PyTorch-ROCm) ----
     def _gen(self):
@@ -129,14 +132,15 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
             sdf, grad, feat = ops.query_points_grad(space_cache, sw, fw, pts, views_per_prompt=B // P,
                                                     radius=self.cfg.radius,
                                                     sdf_bias_radius=float(self.cfg.sdf_bias_params),
-                                                    need_normal=output_normal)
+                                                    need_normal=output_normal, exact_f32=self.exact_f32)
         else:
             with torch.no_grad():
                 packed = ops.planes_pack(space_cache.detach())
                 sdf, grad, feat = ops.query_points(packed, [w.detach() for w in sw], [w.detach() for w in fw], pts,
                                                    views_per_prompt=B // P, radius=self.cfg.radius,
                                                    sdf_bias_radius=float(self.cfg.sdf_bias_params),
-                                                   need_normal=output_normal, need_features=True)
+                                                   need_normal=output_normal, need_features=True,
+                                                   exact_f32=self.exact_f32)
         bias = (pts.reshape(-1, 3) ** 2).sum(-1, keepdim=True).sqrt() - float(self.cfg.sdf_bias_params)
         out = {"sdf": sdf, "sdf_orig": sdf - bias, "features": feat}
         if output_normal:
@@ -151,7 +155,7 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
         pts = points.reshape(B, -1, 3).detach().float()
         sw, fw = self.mlp_weights()
         kw = dict(views_per_prompt=B // space_cache.shape[0], radius=self.cfg.radius,
-                  sdf_bias_radius=float(self.cfg.sdf_bias_params))
+                  sdf_bias_radius=float(self.cfg.sdf_bias_params), exact_f32=self.exact_f32)
         if self._wants_grad(space_cache, (sw,)):
             # (the feature head is evaluated too and gets no upstream gradient: its backward is skipped)
             sdf, _, _ = ops.query_points_grad(space_cache, sw, fw, pts, need_normal=False, **kw)
@@ -172,7 +176,7 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
         sw, _ = self.mlp_weights()
         dw = self.deformation_network.weights()
         kw = dict(views_per_prompt=B // space_cache.shape[0], radius=self.cfg.radius,
-                  sdf_bias_radius=float(self.cfg.sdf_bias_params))
+                  sdf_bias_radius=float(self.cfg.sdf_bias_params), exact_f32=self.exact_f32)
         if self._wants_grad(space_cache, (sw, dw)):
             sdf, deform = ops.query_field_grad(space_cache, sw, dw, pts, **kw)
         else:

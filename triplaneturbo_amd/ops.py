@@ -204,13 +204,14 @@ class _QueryPointsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, space_cache, w1, w2, w3, v1, v2, v3, points, views_per_prompt, radius, sdf_bias_radius,
-                need_normal):
+                need_normal, exact_f32):
         ctx.set_materialize_grads(False)
         packed = planes_pack(space_cache)
         sdf, grad, feat = query_points(packed, (w1, w2, w3), (v1, v2, v3), points, views_per_prompt, radius,
-                                       sdf_bias_radius, need_normal=need_normal, need_features=True)
+                                       sdf_bias_radius, need_normal=need_normal, need_features=True,
+                                       exact_f32=exact_f32)
         ctx.save_for_backward(packed, w1, w2, w3, v1, v2, v3, points)
-        ctx.meta = (views_per_prompt, radius, sdf_bias_radius)
+        ctx.meta = (views_per_prompt, radius, sdf_bias_radius, _lib.TT_Q_EXACT_F32 if exact_f32 else 0)
         if grad is None:
             grad = sdf.new_zeros((sdf.shape[0], 3))
             ctx.mark_non_differentiable(grad)
@@ -220,7 +221,7 @@ class _QueryPointsFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_sdf, g_grad, g_feat):
         packed, w1, w2, w3, v1, v2, v3, points = ctx.saved_tensors
-        vpp, radius, bias_r = ctx.meta
+        vpp, radius, bias_r, qf = ctx.meta
         B, N, _ = points.shape
         P, _, H, W, _ = packed.shape
         wst, keep = _weights_struct((w1, w2, w3), (v1, v2, v3))
@@ -236,32 +237,32 @@ class _QueryPointsFn(torch.autograd.Function):
             if g_sdf is not None or g_grad is not None:
                 ws = torch.empty((B * N, 4), device=packed.device, dtype=torch.float32)
                 st = lib.tt_points_bwd_geo(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius,
-                                           bias_r, 0, _ptr(g_sdf), _ptr(g_grad), _ptr(ws), _ptr(grad_packed),
+                                           bias_r, qf, _ptr(g_sdf), _ptr(g_grad), _ptr(ws), _ptr(grad_packed),
                                            ctypes.byref(gst), _stream())
                 _lib.check(st, "tt_points_bwd_geo")
             if g_feat is not None:
                 st = lib.tt_points_bwd_tex(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius,
-                                           3, 0, _ptr(g_feat), _ptr(grad_packed), ctypes.byref(gst), _stream())
+                                           3, qf, _ptr(g_feat), _ptr(grad_packed), ctypes.byref(gst), _stream())
                 _lib.check(st, "tt_points_bwd_tex")
             g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
         g_points = None
         if ctx.needs_input_grad[7]:
             g_points = torch.empty_like(points)
-            st = lib.tt_points_bwd_x(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius, 0,
+            st = lib.tt_points_bwd_x(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius, qf,
                                      _ptr(g_sdf), _ptr(g_grad), _ptr(g_feat), _ptr(g_points), _stream())
             _lib.check(st, "tt_points_bwd_x")
-        return (g_cache, *gw, g_points, None, None, None, None)
+        return (g_cache, *gw, g_points, None, None, None, None, None)
 
 
 def query_points_grad(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], points: Tensor,
                       views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5,
-                      need_normal: bool = True):
+                      need_normal: bool = True, exact_f32: bool = False):
     """Differentiable per-point decode: sdf (B*N,1), sdf_grad (B*N,3) (zeros, non-differentiable, when
     need_normal is False), features (B*N,3); autograd-connected to space_cache, the six MLP matrices and -- when
-    `points` requires grad -- the points."""
+    `points` requires grad -- the points.  exact_f32: TT_Q_EXACT_F32 in the forward and every backward kernel."""
     return _QueryPointsFn.apply(space_cache, sdf_w[0], sdf_w[1], sdf_w[2], feat_w[0], feat_w[1], feat_w[2],
                                 _chk(points, "points"), int(views_per_prompt), float(radius), float(sdf_bias_radius),
-                                bool(need_normal))
+                                bool(need_normal), bool(exact_f32))
 
 
 class _QueryFieldFn(torch.autograd.Function):
@@ -271,20 +272,21 @@ class _QueryFieldFn(torch.autograd.Function):
     of the three planes is a 96->64->64->3 net with first-layer matrix [U1 U1 U1] on their concatenation)."""
 
     @staticmethod
-    def forward(ctx, space_cache, w1, w2, w3, d1, d2, d3, points, views_per_prompt, radius, sdf_bias_radius):
+    def forward(ctx, space_cache, w1, w2, w3, d1, d2, d3, points, views_per_prompt, radius, sdf_bias_radius,
+                exact_f32):
         ctx.set_materialize_grads(False)
         packed = planes_pack(space_cache)
         sdf, deform = query_field(packed, (w1, w2, w3), (d1, d2, d3), points, views_per_prompt, radius,
-                                  sdf_bias_radius)
+                                  sdf_bias_radius, exact_f32=exact_f32)
         ctx.save_for_backward(packed, w1, w2, w3, d1, d2, d3, points)
-        ctx.meta = (views_per_prompt, radius, sdf_bias_radius)
+        ctx.meta = (views_per_prompt, radius, sdf_bias_radius, _lib.TT_Q_EXACT_F32 if exact_f32 else 0)
         return sdf, deform
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_sdf, g_def):
         packed, w1, w2, w3, d1, d2, d3, points = ctx.saved_tensors
-        vpp, radius, bias_r = ctx.meta
+        vpp, radius, bias_r, qf = ctx.meta
         B, N, _ = points.shape
         P, _, H, W, _ = packed.shape
         d1x3 = d1.repeat(1, 3).contiguous()  # (64, 96) = [U1 U1 U1]
@@ -298,25 +300,27 @@ class _QueryFieldFn(torch.autograd.Function):
             ws = torch.empty((B * N, 4), device=packed.device, dtype=torch.float32)
             g_sdf = g_sdf.contiguous()
             st = lib.tt_points_bwd_geo(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius,
-                                       bias_r, 0, _ptr(g_sdf), None, _ptr(ws), _ptr(grad_packed),
+                                       bias_r, qf, _ptr(g_sdf), None, _ptr(ws), _ptr(grad_packed),
                                        ctypes.byref(gst), _stream())
             _lib.check(st, "tt_points_bwd_geo")
         if g_def is not None:
             g_def = g_def.contiguous()
             st = lib.tt_points_bwd_tex(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, vpp, H, W, radius, 0,
-                                       0, _ptr(g_def), _ptr(grad_packed), ctypes.byref(gst), _stream())
+                                       qf, _ptr(g_def), _ptr(grad_packed), ctypes.byref(gst), _stream())
             _lib.check(st, "tt_points_bwd_tex")
         gw[3] = gw[3].view(64, 3, 32).sum(dim=1)
         g_cache = planes_unpack_grad(grad_packed) if ctx.needs_input_grad[0] else None
-        return (g_cache, *gw, None, None, None, None)
+        return (g_cache, *gw, None, None, None, None, None)
 
 
 def query_field_grad(space_cache: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tensor], points: Tensor,
-                     views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5):
+                     views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5,
+                     exact_f32: bool = False):
     """Differentiable field query: sdf (B*N,1), deformation (B*N,3); autograd-connected to space_cache, the sdf net
     and the deformation net."""
     return _QueryFieldFn.apply(space_cache, sdf_w[0], sdf_w[1], sdf_w[2], deform_w[0], deform_w[1], deform_w[2],
-                               _chk(points, "points"), int(views_per_prompt), float(radius), float(sdf_bias_radius))
+                               _chk(points, "points"), int(views_per_prompt), float(radius), float(sdf_bias_radius),
+                               bool(exact_f32))
 
 
 def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, rc: RenderConfig,
@@ -400,9 +404,18 @@ def render_eval_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Te
 
 
 @torch.no_grad()
-def sample_uniform(n_rays: int, n_samples: int, near: float, far: float, device, jitter: Optional[Tensor] = None):
-    """tt_sample_uniform: level-0 intervals (n_rays, n_samples); jitter (n_rays, n_samples+1) U[0,1) => stratified."""
+def _placement(name: str) -> int:
+    if name not in _lib.PLACEMENTS:
+        raise ValueError(f"placement must be one of {sorted(_lib.PLACEMENTS)}, got {name!r}")
+    return _lib.PLACEMENTS[name]
+
+
+def sample_uniform(n_rays: int, n_samples: int, near: float, far: float, device, jitter: Optional[Tensor] = None,
+                   placement: str = "tt"):
+    """tt_sample_uniform: level-0 intervals (n_rays, n_samples); jitter (n_rays, n_samples+1) U[0,1) => stratified;
+    placement: "tt" | "center" (enum tt_sample_placement, include/tt_abi.h)."""
     device = torch.device(device)
+    place = _placement(placement)
     if device.type != "cuda":
         raise RuntimeError("triplaneturbo_amd samplers run on the GPU only (no CPU fallback)")
     f32 = dict(device=device, dtype=torch.float32)
@@ -412,17 +425,18 @@ def sample_uniform(n_rays: int, n_samples: int, near: float, far: float, device,
         if jitter.shape != (n_rays, n_samples + 1):
             raise ValueError("jitter must be (n_rays, n_samples + 1)")
     with torch.cuda.device(device):
-        st = _lib.load().tt_sample_uniform(n_rays, n_samples, float(near), float(far), _ptr(jitter), _ptr(ts),
-                                           _ptr(te), _stream())
+        st = _lib.load().tt_sample_uniform(n_rays, n_samples, float(near), float(far), _ptr(jitter), place,
+                                           _ptr(ts), _ptr(te), _stream())
     _lib.check(st, "tt_sample_uniform")
     return ts, te
 
 
 @torch.no_grad()
 def sample_importance(t_starts: Tensor, t_ends: Tensor, sdf: Tensor, n_fine: int, inv_std: float,
-                      render_step_size: float, u_jitter: Optional[Tensor] = None):
+                      render_step_size: float, u_jitter: Optional[Tensor] = None, placement: str = "tt"):
     """tt_sample_importance: proposal intervals (n_rays, K) + sdf at their mid-points -> (n_rays, K + n_fine + 1)
-    intervals (proposal edges merged with n_fine + 1 inverse-CDF edges)."""
+    intervals (proposal edges merged with n_fine + 1 inverse-CDF edges placed per `placement`)."""
+    place = _placement(placement)
     t_starts, t_ends, sdf = _chk(t_starts, "t_starts"), _chk(t_ends, "t_ends"), _chk(sdf, "sdf")
     n_rays, K = t_starts.shape
     if t_ends.shape != (n_rays, K) or sdf.numel() != n_rays * K:
@@ -436,8 +450,8 @@ def sample_importance(t_starts: Tensor, t_ends: Tensor, sdf: Tensor, n_fine: int
     ots, ote = torch.empty((n_rays, M), **f32), torch.empty((n_rays, M), **f32)
     with _timed("tt_sample_importance"):
         st = _lib.load().tt_sample_importance(_ptr(t_starts), _ptr(t_ends), _ptr(sdf), n_rays, K, int(n_fine),
-                                              float(inv_std), float(render_step_size), _ptr(u_jitter), _ptr(ots),
-                                              _ptr(ote), _stream())
+                                              float(inv_std), float(render_step_size), _ptr(u_jitter), place,
+                                              _ptr(ots), _ptr(ote), _stream())
     _lib.check(st, "tt_sample_importance")
     return ots, ote
 
@@ -652,8 +666,20 @@ class _CompositeFn(torch.autograd.Function):
     def forward(ctx, opacity, depth, rgb_fg, normal_acc, bg, cam_dist, c2w, rays_per_view, mode, view_group):
         opacity, depth = _chk(opacity, "opacity"), _chk(depth, "depth")
         rgb_fg, normal_acc = _chk(rgb_fg, "rgb_fg"), _chk(normal_acc, "normal_acc")
-        bg, cam_dist, c2w = _chk(bg, "bg_color"), _chk(cam_dist, "camera_distances"), _chk(c2w, "c2w")
+        bg, cam_dist = _chk(bg, "bg_color"), _chk(cam_dist, "camera_distances")
         n = opacity.numel()
+        if rays_per_view <= 0 or n % rays_per_view != 0:
+            raise ValueError(f"n_rays={n} is not a multiple of rays_per_view={rays_per_view}")
+        views = n // rays_per_view
+        if cam_dist.numel() != views:  # (composite() already expanded a 1-element tensor)
+            raise ValueError(f"camera_distances has {cam_dist.numel()} elements, expected one per view ({views})")
+        if c2w is None:
+            if mode != 0:
+                raise ValueError("c2w is required for normal_direction 'camera' / 'front' (renderer :478-530)")
+        else:
+            c2w = _chk(c2w, "c2w", (views, 4, 4))
+        if view_group <= 0 or views % view_group != 0:
+            raise ValueError(f"view_group={view_group} does not divide the number of views ({views})")
         bg_stride = 0 if bg.numel() == 3 else 3
         if bg_stride and bg.numel() != 3 * n:
             raise ValueError("bg_color must have 3 or 3 * n_rays elements")
@@ -667,7 +693,7 @@ class _CompositeFn(torch.autograd.Function):
                                           _ptr(comp_rgb), _ptr(disparity), _ptr(comp_normal), _ptr(vis),
                                           _ptr(vis_white), _stream())
         _lib.check(st, "tt_composite_fwd")
-        ctx.save_for_backward(opacity, depth, rgb_fg, normal_acc, bg, cam_dist, c2w)
+        ctx.save_for_backward(opacity, depth, rgb_fg, normal_acc, bg, cam_dist, *(() if c2w is None else (c2w,)))
         ctx.meta = (n, bg_stride, rays_per_view, mode, view_group)
         ctx.set_materialize_grads(False)
         dummy = comp_rgb.new_zeros(0)
@@ -678,7 +704,8 @@ class _CompositeFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_rgb, g_disp, g_cn, g_vis, g_visw):
-        opacity, depth, rgb_fg, normal_acc, bg, cam_dist, c2w = ctx.saved_tensors
+        opacity, depth, rgb_fg, normal_acc, bg, cam_dist, *rest = ctx.saved_tensors
+        c2w = rest[0] if rest else None
         n, bg_stride, rays_per_view, mode, view_group = ctx.meta
         c = lambda t: None if (t is None or t.numel() == 0) else t.contiguous()
         g_rgb, g_disp, g_cn, g_vis, g_visw = c(g_rgb), c(g_disp), c(g_cn), c(g_vis), c(g_visw)
@@ -697,11 +724,20 @@ class _CompositeFn(torch.autograd.Function):
 
 
 def composite(opacity: Tensor, depth: Tensor, rgb_fg: Tensor, normal_acc: Tensor, bg_color: Tensor,
-              camera_distances: Tensor, c2w: Tensor, rays_per_view: int, normal_direction: str = "camera",
+              camera_distances: Tensor, c2w: Optional[Tensor], rays_per_view: int, normal_direction: str = "camera",
               view_group: int = 1):
     """Per-ray composite of the renderer (renderer :433-530): returns comp_rgb (n,3), disparity (n,1), comp_normal
-    (n,3), comp_normal_cam_vis (n,3) | None, comp_normal_cam_vis_white (n,3) | None."""
+    (n,3), comp_normal_cam_vis (n,3) | None, comp_normal_cam_vis_white (n,3) | None.
+    camera_distances: one per view, or a single element that is broadcast (as it broadcasts in the reference's
+    `camera_distances.reshape(-1,1,1,1)` arithmetic); c2w (views,4,4), may be None for normal_direction 'world'."""
     mode = _COMPOSITE_MODES[normal_direction]
+    views = opacity.numel() // max(int(rays_per_view), 1)
+    camera_distances = camera_distances.reshape(-1).float()
+    if camera_distances.numel() == 1 and views > 1:
+        camera_distances = camera_distances.expand(views)
+    camera_distances = camera_distances.contiguous()
+    if c2w is not None:
+        c2w = c2w.float().contiguous()
     rgb, disp, cn, vis, visw = _CompositeFn.apply(opacity, depth, rgb_fg, normal_acc, bg_color, camera_distances, c2w,
                                                   int(rays_per_view), mode, int(view_group))
     return rgb, disp, cn, (vis if mode == 1 else None), (visw if mode != 0 else None)

@@ -123,10 +123,16 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         # Measured at the reference training shapes (42^2 + 40^2 rays, 193 samples): sb 1/2/4/8/16 =
         # 14.4/12.9/12.5/12.3/12.8 ms per PatchRenderer forward+backward.
         self.tile_sb_importance = 8
-        # eval renders (no autograd) stop marching a ray once its transmittance is below this and skip texture decodes
-        # of weights below eps / S (tt_render_eval): per-ray error of opacity / comp_rgb < 2 eps.  0 = march everything
-        # like the reference (renderer :317-324 keeps all samples).  Not a reference knob, so not in Config.
-        self.eval_termination_eps = 1.0e-4
+        # where the sampler places its edges in cdf space: "tt" | "center" (sampler.py; nerfacc's own convention is
+        # unverifiable in this build, so the choice is explicit).  Not a reference knob, so not in Config.
+        self.sampler_placement = "tt"
+        # OPT-IN approximation for eval renders without autograd (tt_render_eval): eps > 0 stops marching a ray once its
+        # transmittance is below eps and skips texture decodes of weights below eps / S; per-ray error of opacity and
+        # comp_rgb < 2 eps, of depth < eps * far, of z_variance / comp_normal likewise O(eps) (measured at eps = 1e-4 on
+        # the bench scene: opacity 1.0e-4, depth 1.7e-4, 17 % fewer geometry tile steps).
+        # Default 0 = march every sample like the reference (renderer :317-324): a validation image rendered through
+        # the plugin equals the reference's.  Not a reference knob, so not in Config.
+        self.eval_termination_eps = 0.0
 
     # ------------------------------------------------------------------------------------------
     def _inv_std_value(self) -> float:
@@ -139,6 +145,18 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         if getattr(self, "_inv_std_cache", (None, None))[0] != key:
             self._inv_std_cache = (key, min(max(math.exp(float(p.detach()) * 10.0), 1.0e-6), 1.0e6))
         return self._inv_std_cache[1]
+
+    def set_inv_std(self, inv_std: float) -> None:
+        """Write the variance parameter (inv_std = exp(10 p)) and refresh the cached host value.  Writes through
+        `variance._inv_std.data` bypass the tensor version counter and are NOT seen by the cache: use this, assign
+        with `copy_` / `load_state_dict` (both detected), or call `update_step` (which drops the cache)."""
+        with torch.no_grad():
+            self.variance._inv_std.fill_(math.log(float(inv_std)) / 10.0)
+        self._inv_std_cache = (None, None)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._inv_std_cache = (None, None)
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def _render_config(self) -> ops.RenderConfig:
         g = self.geometry.cfg
@@ -163,7 +181,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         return sampler.importance_sampling(
             sdf_fn, n_rays, self.cfg.num_samples_per_ray_importance, self.cfg.num_samples_per_ray,
             self.cfg.near_plane, self.cfg.far_plane, rc.inv_std, self.render_step_size, device=rays_o.device,
-            stratified=self.randomized, generator=generator)
+            stratified=self.randomized, generator=generator, placement=self.sampler_placement)
 
     def forward(self, rays_o: Tensor, rays_d: Tensor, light_positions: Optional[Tensor] = None,
                 bg_color: Optional[Tensor] = None, noise: Optional[Tensor] = None,
@@ -213,6 +231,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         return out
 
     def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False) -> None:
+        self._inv_std_cache = (None, None)  # one read-back per step at most; also catches `.data` writes
         self.rgb_grad_shrink = C(self.cfg.rgb_grad_shrink, epoch, global_step)  # renderer :548-553
         self.cos_anneal_ratio = 1.0 if self.cfg.cos_anneal_end_steps == 0 else min(
             1.0, global_step / self.cfg.cos_anneal_end_steps)  # neus_volume_renderer.py:385-389
