@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- rendered rays/s (fwd+bwd) of the triplane volume-render hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W [--config 3]
 
@@ -14,14 +14,20 @@ Workloads (weak scaling: per-GPU work is fixed as N grows):
              1 view of 256x256 rays, 128 uniform samples on [0.1, 4.0].
   --config 3 (BASELINE.json configs[3]: 64 prompts sharded 8-way): per GPU 8 prompts (8,6,32,256,256), one 256x256 view
              each, same samples; rank r renders prompts shard_prompts(8 N, r, N).
-Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.  Roofline arithmetic:
-profiles/README.md.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.  Every number of the line can be
+recomputed from profiles/ with the arithmetic in profiles/README.md.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
 import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -30,60 +36,63 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # ---- algorithmic work per ray-sample --------------------------------------------
-# MACs of each kernel by the pipe that executes them (recompute and the scatter-combine GEMM are NOT algorithmic work
-# and are not counted): "f16x3" = 2-term split-fp16 products, 3 x v_mfma_f32_32x32x16_f16 per 32x32x16 tile;
-# "f32" = v_mfma_f32_32x32x2_f32; "valu" = the 64-wide output layers (w3 / V3 rows), plain FMAs.
-KERNELS = {
-    "tt_render_fwd": {  # k_decode_rays<N,TEX> (+ k_march_fwd, ~0.07 ms): sdf 6208 + feat 10432 + normal chain 6208
+# bytes_8d: SURVEY 8(d)'s algorithmic texel bytes: forward reads 6 planes x 4 corners x 32 ch x 4 B = 3072; each
+#           backward kernel ACCUMULATES the gradient of its three planes = 1536 (the re-gather of the recompute is NOT
+#           algorithmic work, exactly like the recomputed FLOPs).
+# macs:     algorithmic multiply-adds by the pipe that executes them in the default build (recompute and the
+#           scatter-combine GEMM are not counted): "f16x3" = 2-term split-fp16 products (3 x v_mfma_f32_32x32x16_f16 per
+#           32x32x16 tile), "f32" = v_mfma_f32_32x32x2_f32, "valu" = the 64-wide output layers (plain FMAs).
+ALG = {
+    "tt_render_fwd": {  # k_decode_rays<N,TEX> (+ k_march_fwd): sdf 6208 + feat 10432 + normal chain 6208 = 22848 MAC
+        "device_kernel": "k_decode_rays",
+        "bytes_8d": 6 * 4 * 32 * 4,
         "macs": {"f16x3": 2048 + 4096 + 6144 + 4096 + 4096 + 2048, "f32": 0, "valu": 64 + 192 + 64},
-        "bytes": 6 * 4 * 32 * 4,  # 6 planes x 4 corners x 32 ch x 4 B texel reads = 3072
     },
-    "tt_render_bwd_geo": {  # (k_march_bwd, ~0.1 ms +) k_decode_bwd_geo: value chain + gradient chain, act + weights
+    "tt_render_bwd_geo": {  # (k_march_bwd +) k_decode_bwd_geo: value chain + gradient chain, activations + weights
+        "device_kernel": "k_decode_bwd_geo",
+        "bytes_8d": 3 * 4 * 32 * 4,
         "macs": {"f16x3": 2048 + 4096 + 4096 + 2048 + 2048 + 4096, "f32": 2048 + 4096, "valu": 256},
-        "bytes": 3 * 4 * 32 * 4 * 2,  # geometry planes: gather 1536 + gradient scatter 1536
     },
     "tt_render_bwd_tex": {  # k_decode_bwd_tex: activations 10432 + weight gradients 10432
-        "macs": None,  # filled in by _tex_macs(): depends on the build (which products run on which pipe)
-        "bytes": 3 * 4 * 32 * 4 * 2,
+        "device_kernel": "k_decode_bwd_tex",
+        "bytes_8d": 3 * 4 * 32 * 4,
+        "macs": {"f16x3": 4096 + 6144, "f32": 4096 + 6144, "valu": 384},
     },
 }
 BYTES_MARCH_FWD = 44        # t_starts, t_ends, sdf, sdf_grad(3), features(3) read; weights, trans written
 BYTES_MARCH_BWD = 68        # the 9 above + trans + g_sdf_grad(3) read; (d sdf, d sdf_grad) float4 written
-PEAK = {"f32": 157.3, "f16": 2500.0}        # dense MFMA TFLOP/s, MI355X_MICROARCH.md
-PEAK["f16x3"] = PEAK["f16"] / 3.0           # algorithmic FLOP/s of a 3-MFMA split product at 100 % of the fp16 pipe
-PEAK["valu"] = 157.3
+PEAK_F32_TFLOPS = 157.3     # dense fp32-input MFMA = fp32 vector peak (MI355X_MICROARCH.md): SURVEY 8(d)'s MLP roofline
+PEAK_F16_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
+PEAK = {"f32": PEAK_F32_TFLOPS, "valu": PEAK_F32_TFLOPS, "f16x3": PEAK_F16_TFLOPS / 3.0}
 PEAK_HBM_GBS = 8000.0
-
-
-def _tex_macs(exact):
-    # activations: V3^T cbar (192, valu), V2^T k2bar (4096), V1^T k1bar (6144); weights: dV3 (192, valu), dV2 (4096),
-    # dV1 (6144)
-    if exact:
-        return {"f16x3": 0, "f32": 4096 + 6144 + 4096 + 6144, "valu": 384}
-    return {"f16x3": 4096 + 6144, "f32": 4096 + 6144, "valu": 384}  # activation chain split-fp16, outer products fp32
+DTYPE = "f32 (2xfp16-split products, 22-bit)"
+DTYPE_EXACT = "f32 (fp32-input MFMA)"
 
 
 def kernel_roofline(name, ms, n_samples, exact):
-    """max(algorithmic bytes / HBM peak, algorithmic FLOP / peak of the pipe mix) / measured time."""
-    k = KERNELS[name]
-    macs = dict(k["macs"] or _tex_macs(exact))
+    """Both forms of  max(algorithmic bytes / HBM peak, algorithmic FLOP / MFMA peak) / measured time :
+      frac_8d       SURVEY 8(d) literally: bytes_8d / 8 TB/s against ALL algorithmic FLOP / 157.3 TFLOP/s (the fp32-MFMA
+                    roofline 8(d) names).  A value > 1 means the kernel beats both 8(d) ceilings -- possible because the
+                    planes are cache-resident (no HBM traffic per texel) and the products run on the fp16 pipe.
+      frac_pipe_mix the same with every FLOP priced on the pipe that executes it (split-fp16 products: 2500/3 TFLOP/s).
+    """
+    a = ALG[name]
+    macs = dict(a["macs"])
     if exact:  # every matrix product on the fp32 MFMA
         macs = {"f16x3": 0, "f32": macs["f16x3"] + macs["f32"], "valu": macs["valu"]}
-    flop = 2.0 * sum(macs.values()) * n_samples
-    t_mfma = sum(2.0 * m * n_samples / (PEAK[p] * 1e12) for p, m in macs.items()) * 1e3  # ms at 100 % of each pipe
-    t_hbm = k["bytes"] * n_samples / (PEAK_HBM_GBS * 1e9) * 1e3
-    eff_peak = flop / (t_mfma * 1e-3) / 1e12
-    bound = "hbm" if t_hbm >= t_mfma else "mfma"
-    r = {"avg_ms": round(ms, 4), "alg_flop_per_sample": int(2 * sum(macs.values())), "alg_bytes_per_sample": k["bytes"],
-         "t_mfma_ms": round(t_mfma, 4), "t_hbm_ms": round(t_hbm, 4), "mfma_peak_of_pipe_mix_tflops": round(eff_peak, 1),
-         "tflops": round(flop / (ms * 1e-3) / 1e12, 2), "alg_GBs": round(k["bytes"] * n_samples / (ms * 1e-3) / 1e9, 1),
-         "bound": bound, "frac": round(max(t_hbm, t_mfma) / ms, 4)}
-    if r["frac"] > 1.0:
-        # more algorithmic bytes per second than HBM can deliver: the texel gathers are served by L1/L2/Infinity
-        # Cache (the planes are 50 MB per prompt), so HBM is not what bounds this kernel; its matrix work is
-        r.update(bound="mfma", frac=round(t_mfma / ms, 4),
-                 note="algorithmic texel bytes exceed the HBM roofline (cache-resident planes): priced on MFMA only")
-    return r
+    flop_per_sample = 2 * sum(macs.values())
+    flop = float(flop_per_sample) * n_samples
+    t_hbm = a["bytes_8d"] * n_samples / (PEAK_HBM_GBS * 1e9) * 1e3                       # ms at 8 TB/s
+    t_f32 = flop / (PEAK_F32_TFLOPS * 1e12) * 1e3                                         # ms at 157.3 TFLOP/s
+    t_mix = sum(2.0 * m * n_samples / (PEAK[p] * 1e12) for p, m in macs.items()) * 1e3    # ms at each pipe's peak
+    return {
+        "avg_ms": round(ms, 4), "alg_bytes_per_sample": a["bytes_8d"], "alg_flop_per_sample": int(flop_per_sample),
+        "alg_GBs": round(a["bytes_8d"] * n_samples / (ms * 1e-3) / 1e9, 1),
+        "alg_tflops": round(flop / (ms * 1e-3) / 1e12, 2),
+        "t_hbm_ms": round(t_hbm, 4), "t_f32mfma_ms": round(t_f32, 4), "t_pipe_mix_ms": round(t_mix, 4),
+        "bound_8d": "hbm" if t_hbm >= t_f32 else "mfma", "frac_8d": round(max(t_hbm, t_f32) / ms, 4),
+        "bound_pipe_mix": "hbm" if t_hbm >= t_mix else "mfma", "frac_pipe_mix": round(max(t_hbm, t_mix) / ms, 4),
+    }
 
 
 def make_inputs(rank, world, device, config, R=256, Hh=256, Ww=256, S=128):
@@ -112,14 +121,19 @@ def make_inputs(rank, world, device, config, R=256, Hh=256, Ww=256, S=128):
                 te=te.to(device).repeat(P, 1), bg=torch.ones(3, device=device), proj=proj, prompts=prompts)
 
 
-def loss_fn(out, proj):
+def loss_fn(out, proj, fused_eikonal=False):
     """G6 loss: seeded projections of the image-space outputs + sparsity + eikonal
-    (multiprompt_dual_renderer_multistep_generator.py:635, :696-699)."""
+    (multiprompt_dual_renderer_multistep_generator.py:635, :696-699).  fused_eikonal: the eikonal term through
+    ops.eikonal_loss (tt_eikonal_fwd / _bwd: one kernel each way, same value) instead of five torch kernels each way."""
     loss = 0.0
     for k, p in proj.items():
         loss = loss + (out[k] * p).sum()
     loss = loss + (out["opacity"] ** 2 + 0.01).sqrt().mean()
-    loss = loss + ((torch.linalg.norm(out["sdf_grad"], ord=2, dim=-1) - 1.0) ** 2).mean()
+    if fused_eikonal:
+        from triplaneturbo_amd import ops
+        loss = loss + ops.eikonal_loss(out["sdf_grad"])
+    else:
+        loss = loss + ((torch.linalg.norm(out["sdf_grad"], ord=2, dim=-1) - 1.0) ** 2).mean()
     return loss
 
 
@@ -127,7 +141,8 @@ def cpu_baseline(n_rays_sample=256, S=128, R=256, budget_s=25.0):
     """The CPU oracle (pure-torch restatement of the reference renderer) timed on this host: same planes,
     cameras, samples and loss as --config 1, on one image row through the middle of the object (`n_rays_sample`
     rays).  torch's intra-op threading does not scale on these gather/scatter-heavy ops (on a 256-core host 256
-    threads are ~40x SLOWER than 8), so the thread count is picked by a short calibration and reported as `cores`."""
+    threads are ~40x SLOWER than 8), so the thread count is picked by a short calibration and reported as `cores`;
+    one pass at os.cpu_count() threads (SURVEY 8d's literal setting) is timed as well when it fits the budget."""
     from oracle import cpu_ref as O
     host_cores = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
@@ -157,17 +172,24 @@ def cpu_baseline(n_rays_sample=256, S=128, R=256, budget_s=25.0):
         dt = step()
         if best_t is None or dt < best_t:
             best_t, best_n = dt, nt
-        if time.perf_counter() - t_begin > budget_s * 0.6:
+        if time.perf_counter() - t_begin > budget_s * 0.5:
             break
     torch.set_num_threads(best_n)
     times = [best_t]
-    while time.perf_counter() - t_begin < budget_s and len(times) < 5:
+    while time.perf_counter() - t_begin < budget_s * 0.75 and len(times) < 5:
         times.append(step())
     dt = sorted(times)[len(times) // 2]
+    all_cores = None
+    if host_cores != best_n and time.perf_counter() - t_begin < budget_s * 0.8:
+        torch.set_num_threads(host_cores)
+        all_cores = {"cores": host_cores, "value": rows * 256 / step(), "unit": "rays/s",
+                     "note": "one un-warmed pass with torch.set_num_threads(os.cpu_count()) (SURVEY 8d's literal setting)"}
+        torch.set_num_threads(best_n)
     return {"value": rows * 256 / dt, "unit": "rays/s", "cores": best_n, "kind": "port",
             "sample": f"image row(s) {r0}..{r0 + rows - 1} = {rows * 256} rays (of 65536) x {S} samples, fwd+bwd of the "
                       f"same loss, fp32 torch CPU oracle, median {dt:.2f} s/pass, {best_n} threads (best of a "
-                      f"calibration over 4..32; host has {host_cores} cores)"}
+                      f"calibration over 4..32; host has {host_cores} cores)",
+            "all_cores": all_cores}
 
 
 def march_roofline(inp, rc, ops, reps):
@@ -201,6 +223,145 @@ def march_roofline(inp, rc, ops, reps):
             "note": "algorithmic bytes per sample (44 fwd / 68 bwd) x samples per launch over the HIP-event duration"}
 
 
+# ---- HBM-side traffic of the kernels: two separate rocprofv3 --pmc passes over a short run of this same script ---------
+def pmc_traffic(config, timeout_s=240):
+    """FETCH_SIZE and WRITE_SIZE (TCC) per kernel launch, each in its OWN `rocprofv3 --pmc <counter> --kernel-trace` pass
+    (they do not fit one pass: MI355X_MICROARCH.md, rocprofv3 PMC slots) over `bench.py --pmc-child` (3 steps).  Bytes =
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KiB, and on gfx950 FETCH_SIZE reports half of a wide
+    coalesced read (same guide; calibrated in this workload on k_planes_pack: 50.3 MB read + 50.3 MB written)."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    per = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="tt_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(config), "--steps", "2", "--warmup", "1"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {ctr} timed out"
+        acc, cnt = {}, {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] != ctr:
+                    continue
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+                acc[k] = acc.get(k, 0.0) + float(row["Counter_Value"])
+                cnt[k] = cnt.get(k, 0) + 1
+        shutil.rmtree(d, ignore_errors=True)
+        if not acc:
+            return None, f"rocprofv3 --pmc {ctr} produced no counters (rc {r.returncode}): {r.stderr[-300:]}"
+        per[ctr] = {k: acc[k] / cnt[k] for k in acc}
+    out = {}
+    for k in per["FETCH_SIZE"]:
+        if k in per["WRITE_SIZE"]:
+            out[k] = {"fetch_KiB": round(per["FETCH_SIZE"][k], 1), "write_KiB": round(per["WRITE_SIZE"][k], 1),
+                      "bytes": int((2.0 * per["FETCH_SIZE"][k] + per["WRITE_SIZE"][k]) * 1024)}
+    return out, None
+
+
+# ---- SURVEY 8(d) secondary (reference-faithful) workloads, outside the timed region ----------------------------------
+def secondary_workloads(device, inp, steps=5, warmup=2):
+    """(i) configs[1] with the reference's sampler: 128 proposal + 64 importance samples -> 193 intervals per ray
+    (proposal decode + tt_sample_importance + render + backward through the plugin);  (ii) the reference TRAINING shape:
+    2 prompts x 4 views of 128x128 rays through PatchRenderer (42x42 global + 40x40 patch rays), 193 samples."""
+    import triplaneturbo_amd as tt
+    from triplaneturbo_amd import synthetic
+    torch.manual_seed(0)
+    geo = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(device)
+    with torch.no_grad():
+        for dst, src in zip(list(geo.sdf_network.weights()) + list(geo.feature_network.weights()), inp["sw"] + inp["fw"]):
+            dst.copy_(src)
+    base = dict(estimator="importance", trainable_variance=False, learned_variance_init=0.4605, num_samples_per_ray=64,
+                num_samples_per_ray_importance=128, near_plane=0.1, far_plane=4.0, randomized=True)
+    mat, bgm = tt.find("no-material")({}), tt.find("solid-color-background")({})
+    res = {}
+
+    def timed(step):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    # (i) importance-sampled configs[1]
+    r1 = tt.find("generative-space-sdf-volume-renderer")(base, geometry=geo, material=mat, background=bgm).to(device)
+    r1.train()
+    cache = inp["cache"][:1].detach().clone().requires_grad_(True)
+    kw = dict(space_cache=cache, text_embed=torch.zeros(1, 77, 1024), camera_distances=inp["cd"][:1], c2w=inp["c2w"][:1])
+    ro, rd, bg = inp["ro"][:1], inp["rd"][:1], inp["bg"]
+    proj = {k: v[:1] for k, v in inp["proj"].items()}
+
+    def step1():
+        out = r1(ro, rd, None, bg, **kw)
+        loss = loss_fn(out, proj, fused_eikonal=True)
+        for p_ in [cache] + list(geo.parameters()):
+            p_.grad = None
+        loss.backward()
+
+    ms = timed(step1)
+    res["importance_193"] = {
+        "workload": "configs[1] planes / camera / loss with the reference's sampler: 128 stratified proposal intervals "
+                    "(sdf-only decode) + 64 importance samples -> 193 intervals per ray, 256x256 rays, fwd+bwd incl. the "
+                    "sampling", "ms_per_step": round(ms, 3), "rays_per_s": round(65536 / (ms * 1e-3), 1),
+        "samples_per_ray": 193, "proposal_decodes_per_ray": 128}
+    # (ii) PatchRenderer training shape
+    r2 = tt.find("patch-renderer")({"patch_size": 40, "global_downsample": 3,
+                                    "base_renderer_type": "generative-space-sdf-volume-renderer", "base_renderer": base},
+                                   geometry=geo, material=mat, background=bgm).to(device)
+    r2.train()
+    P, NV = 2, 4
+    gen = torch.Generator().manual_seed(1)
+    cache2 = (torch.randn(P, 6, 32, 256, 256, generator=gen) * 0.5).to(device).requires_grad_(True)
+    ro2, rd2, c2w2, cd2 = synthetic.make_cameras(P * NV, 128, 128)
+    kw2 = dict(space_cache=cache2, text_embed=torch.zeros(P, 77, 1024), camera_distances=cd2.to(device),
+               c2w=c2w2.to(device))
+    ro2, rd2 = ro2.to(device), rd2.to(device)
+
+    def step2():
+        out = r2(ro2, rd2, None, bg, **kw2)
+        from triplaneturbo_amd import ops
+        loss = out["comp_rgb"].mean() + (out["opacity"] ** 2 + 0.01).sqrt().mean() + ops.eikonal_loss(out["sdf_grad"])
+        for p_ in [cache2] + list(geo.parameters()):
+            p_.grad = None
+        loss.backward()
+
+    ms = timed(step2)
+    n_rays = P * NV * (42 * 42 + 40 * 40)
+    res["patch_renderer_training_shape"] = {
+        "workload": "reference training shape (configs/TriplaneTurbo_v1.yaml:8-9,133-150): 2 prompts x 4 views, 128x128 "
+                    "rays through PatchRenderer = 42x42 global + 40x40 patch rays per view, 193 samples, planes 256^2, "
+                    "fwd+bwd incl. the sampling",
+        "ms_per_step": round(ms, 3), "rays_per_step": n_rays, "rays_per_s": round(n_rays / (ms * 1e-3), 1)}
+    return res
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run with N ranks on this node
+    (one process per GPU, rendezvous on 127.0.0.1)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,18 +371,32 @@ def main():
                     help="1 = BASELINE configs[1] per GPU (headline); 3 = configs[3]: 8 prompts x 256x256 rays per GPU")
     ap.add_argument("--exact-f32", action="store_true",
                     help="A/B: every matrix product on the fp32-input MFMA (TT_R_EXACT_F32) instead of split-fp16")
+    ap.add_argument("--torch-loss", action="store_true",
+                    help="A/B: the eikonal term of the G6 loss with plain torch ops instead of ops.eikonal_loss")
+    ap.add_argument("--graph", action="store_true",
+                    help="A/B: capture the step in a hipGraph (torch.cuda.graph) and time replays instead of eager steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes (roofline.traffic = null)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exact-f32 sub-result and the secondary workloads")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # body of a rocprofv3 pass: steps only
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and not args.pmc_child:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
+                         f"or run `python bench.py --gpus {args.gpus}` without a launcher (it spawns the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    dev_index = local_rank % torch.cuda.device_count()  # (two ranks may share a GPU in the 1-GPU smoke test)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev  # (ranks share a GPU only in the 1-GPU smoke test of the N > 1 path)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -245,16 +420,21 @@ def main():
     P = inp["cache"].shape[0]
     rc = ops.RenderConfig(exact_f32=args.exact_f32)
     bucket = FlatGradBucket(inp["sw"] + inp["fw"])  # MLP grads = views of one buffer: one collective, no cat / copies
+    fused = not args.torch_loss
 
-    def step():
-        inp["cache"].grad = None
-        bucket.zero_()
-        out = functional.volume_render(inp["cache"], inp["sw"], inp["fw"], inp["ro"], inp["rd"], inp["ts"], inp["te"],
-                                       inp["bg"], inp["cd"], inp["c2w"], rc, training=True)
-        loss = loss_fn(out, inp["proj"])
-        loss.backward()
-        bucket.all_reduce(dist)  # DDP-equivalent: one flat RCCL all-reduce on the compute stream
-        return loss
+    def make_step(rcfg):
+        def step():
+            inp["cache"].grad = None
+            bucket.zero_()
+            out = functional.volume_render(inp["cache"], inp["sw"], inp["fw"], inp["ro"], inp["rd"], inp["ts"],
+                                           inp["te"], inp["bg"], inp["cd"], inp["c2w"], rcfg, training=True)
+            loss = loss_fn(out, inp["proj"], fused_eikonal=fused)
+            loss.backward()
+            bucket.all_reduce(dist)  # DDP-equivalent: one flat RCCL all-reduce on the compute stream
+            return loss
+        return step
+
+    step = make_step(rc)
 
     def barrier():
         if world > 1:
@@ -262,66 +442,123 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        loss = step()
+    if args.pmc_child:  # body of one rocprofv3 --pmc pass: the same steps, nothing else
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        return
+
+    graph = None
+    if args.graph:  # the whole step (incl. the all-reduce when N > 1 is NOT captured: N = 1 only) as one hipGraph
+        if world > 1:
+            raise SystemExit("--graph is an N = 1 A/B")
+        static_g = torch.zeros_like(inp["cache"])
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = step()
+            static_g.copy_(inp["cache"].grad)
+        run = graph.replay
+    else:
+        run = step
+
     timer = ops.KernelTimer()
-    ops.set_kernel_timer(timer)
+    if graph is None:
+        ops.set_kernel_timer(timer)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()
-        loss = step()
+        r = run()
+        if r is not None:
+            loss = r
         b.record()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    dt = dt_local
+    per_rank_ms, allreduce_us, ranks_seen = None, None, None
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
+        # (gloo -- the 1-GPU smoke test of this path -- all-reduces CUDA tensors but gathers CPU tensors only)
+        tmax = torch.tensor([dt_local], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        allt = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(allt, tmax)
+        per_rank_ms = [round(float(t) / args.steps * 1e3, 4) for t in allt]
+        dt = max(float(t) for t in allt)
+        # the collective alone: the flat 66.6 KB MLP-gradient all-reduce, HIP events around 50 back-to-back calls
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            bucket.all_reduce(dist)
+        barrier()
+        e0.record()
+        for _ in range(50):
+            bucket.all_reduce(dist)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_us = round(e0.elapsed_time(e1) / 50 * 1e3, 2)
+        info = [None] * world
+        props = torch.cuda.get_device_properties(dev_index)
+        dist.all_gather_object(info, {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": props.name,
+                                      "uuid": str(getattr(props, "uuid", ""))})
+        ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": info,
+                      "distinct_devices": len({(i["uuid"], i["device"]) for i in info})}
     ms_per_step = dt / args.steps * 1e3
     n_rays = P * Hh * Ww
     value = n_rays * world * args.steps / dt
 
     if rank == 0:
         step_ms = sorted(a.elapsed_time(b) for a, b in ev)
-        ksum = timer.summary(median=True)  # label -> (median ms, launches)
         n_samples = n_rays * S
+        if graph is not None:  # per-kernel HIP events cannot be recorded inside a replay: time eager steps for them
+            ops.set_kernel_timer(timer)
+            for _ in range(5):
+                step()
+            ops.set_kernel_timer(None)
+        ksum = timer.summary(median=True)  # label -> (median ms, launches)
         kernels = {k: dict(kernel_roofline(k, ms, n_samples, args.exact_f32), launches=n) for k, (ms, n) in ksum.items()
-                   if k in KERNELS}
+                   if k in ALG}
+        traffic, traffic_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_traffic(args.config)
+        if traffic:
+            for k, v in kernels.items():
+                dk = ALG[k]["device_kernel"]
+                if dk in traffic:
+                    v["pmc"] = dict(traffic[dk], kernel=dk)
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         kd = kernels[dom]
-        if kd["bound"] == "hbm":
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": kd["alg_GBs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": kd["frac"]}
+        if kd["bound_8d"] == "hbm":
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": kd["alg_GBs"], "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         else:
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": kd["tflops"],
-                        "peak": kd["mfma_peak_of_pipe_mix_tflops"], "unit": "TFLOP/s", "frac": kd["frac"]}
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": kd["alg_tflops"], "peak": PEAK_F32_TFLOPS,
+                        "unit": "TFLOP/s"}
         roofline.update(
-            traffic=None, avg_kernel_ms=kd["avg_ms"],
-            note="SURVEY 8(d): max(algorithmic bytes / 8 TB/s, algorithmic FLOP / peak of the pipe mix the kernel runs) "
-                 "over the median HIP-event duration of the entry point on the launch stream; `traffic` (PMC bytes) is "
-                 "not collected by this run -- see traffic_profile")
-        try:  # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE): a profile, not
-            # a measurement of this run
-            src = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic_bytes.json"))[-1]
-            tb = json.load(open(os.path.join(ROOT, "profiles", src)))
-            key = {"tt_render_fwd": "k_decode_rays", "tt_render_bwd_geo": "k_decode_bwd_geo",
-                   "tt_render_bwd_tex": "k_decode_bwd_tex"}[dom]
-            roofline["traffic_profile"] = {"bytes_per_launch": next(v for k, v in tb.items() if key in k),
-                                           "source": f"profiles/{src}"}
-        except Exception:
-            pass
-        # the bandwidth-bound stage: the ray march (k_march_fwd / k_march_bwd), re-timed on the live buffers of one
-        # more forward, outside the timed region (inside tt_render_fwd / tt_render_bwd_geo they run back to back with
-        # the decode kernels, so the entry-point timers above cannot separate them)
+            frac=kd["frac_8d"], definition="frac_8d", frac_pipe_mix=kd["frac_pipe_mix"], avg_kernel_ms=kd["avg_ms"],
+            traffic=(kd.get("pmc") or {}).get("bytes"),
+            traffic_source=("two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this script in this run: "
+                            "(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch of " + ALG[dom]["device_kernel"])
+            if traffic else f"not collected: {traffic_err}",
+            note="SURVEY 8(d) literally: the dominant kernel's max(algorithmic bytes / 8 TB/s, algorithmic FLOP / 157.3 "
+                 "TFLOP/s fp32-MFMA) over its median HIP-event duration on the launch stream (entry point = march + "
+                 "decode kernels where fused); algorithmic bytes: 3072 B/sample forward reads, 1536 B/sample accumulated "
+                 "by each backward kernel (the recompute's re-gather is not algorithmic work); frac_pipe_mix prices each "
+                 "FLOP on the pipe that executes it (split-fp16: 2500/3 TFLOP/s)")
         hbm = march_roofline(inp, rc, ops, args.steps)
         t_all = sum(v["avg_ms"] for v in kernels.values()) * 1e-3
-        # SURVEY 8(d) "sampling stage": 6144 algorithmic B/sample (gather + scatter) over the time of ALL fused kernels
-        hbm["fused_gather_scatter"] = {"GBs": round(6144 * n_samples / t_all / 1e9, 1),
-                                       "frac_of_hbm_peak": round(6144 * n_samples / t_all / 1e9 / PEAK_HBM_GBS, 4),
-                                       "note": "served mostly by L1/L2/Infinity Cache (planes: 50 MB per prompt)"}
-        mlp_flop = sum(v["alg_flop_per_sample"] for v in kernels.values()) * n_samples
+        stage = {  # whole-step stage rooflines over the time of ALL fused kernels
+            "kernel_time_ms": round(t_all * 1e3, 4),
+            "sampling_stage": {"alg_bytes_per_sample": 6144, "GBs": round(6144 * n_samples / t_all / 1e9, 1),
+                               "frac_of_hbm_peak": round(6144 * n_samples / t_all / 1e9 / PEAK_HBM_GBS, 4),
+                               "note": "served mostly by L1/L2/Infinity Cache (planes: 50 MB per prompt)"},
+            "mlp_stage": {"alg_flop_per_sample": 137088, "tflops": round(137088.0 * n_samples / t_all / 1e12, 1),
+                          "frac_of_f32_mfma_peak": round(137088.0 * n_samples / t_all / 1e12 / PEAK_F32_TFLOPS, 4)},
+            "glue_ms": round(statistics.median(step_ms) - t_all * 1e3, 4),
+        }
         cfg_name = {1: "BASELINE configs[1]: per GPU 1 triplane (1,6,32,256,256), 1 view 256x256 rays",
                     3: "BASELINE configs[3]: per GPU 8 prompts (8,6,32,256,256) of a batch sharded over the GPUs, one "
                        "256x256 view each"}[args.config]
@@ -330,20 +567,47 @@ def main():
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_median_hipevent": round(statistics.median(step_ms), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE_EXACT if args.exact_f32 else DTYPE,
             "dtype_note": ("TT_R_EXACT_F32: every matrix product on v_mfma_f32_32x32x2_f32" if args.exact_f32 else
-                           "fp32 storage, accumulation and element-wise math; mat-vec products as 2-term split-fp16 "
-                           "(hi + lo/2048, 22-bit significands, 3 fp16 MFMAs, fp32 accumulate) except where `kernels` "
-                           "lists f32 MACs; --exact-f32 runs everything on the fp32 MFMA"),
+                           "fp32 storage, accumulation and element-wise math; every mat-vec product as a 2-term "
+                           "split-fp16 product (v = hi + lo, operands normalised to the top of the fp16 range, 22-bit "
+                           "significands, 3 x v_mfma_f32_32x32x16_f16 into one fp32 accumulator) except the f32 MACs "
+                           "listed in profiles/README.md (weight-gradient outer products, texture scatter GEMM); the "
+                           "strict-fp32 number of the same build is `exact_f32` below"),
             "data": "synthetic",
             "config": {"workload": cfg_name + ", 128 uniform samples on [0.1,4.0], fwd + bwd of the G6 loss (d/d planes + "
                                               "d/d 6 MLP matrices, second-order normal path included)",
                        "rays_per_gpu": n_rays, "samples_per_ray": S, "prompts_per_gpu": P, "parallelism": f"dp{world}",
-                       "loss": float(loss.detach())},
-            "roofline": roofline, "roofline_hbm": hbm, "kernels": kernels,
-            "mlp_stage": {"alg_tflop_per_step": round(mlp_flop / 1e12, 4),
-                          "tflops_over_kernel_time": round(mlp_flop / t_all / 1e12, 1)},
+                       "loss": float(loss.detach()), "eikonal": "torch ops" if args.torch_loss else "ops.eikonal_loss",
+                       "mode": "hipGraph replay" if graph is not None else "eager"},
+            "roofline": roofline, "roofline_hbm": hbm, "kernels": kernels, "stages": stage,
         }
+        if world > 1:
+            line["multi_gpu"] = {"per_rank_ms_per_step": per_rank_ms, "allreduce_us": allreduce_us,
+                                 "allreduce_bytes": bucket.flat_grad.numel() * 4, "rccl": ranks_seen}
+        if world == 1 and not args.no_extras and not args.exact_f32:
+            # strict-fp32 sub-result of the same build (driver-visible): 5 steps with TT_R_EXACT_F32
+            rcx = ops.RenderConfig(exact_f32=True)
+            stepx = make_step(rcx)
+            for _ in range(2):
+                stepx()
+            tx = ops.KernelTimer()
+            ops.set_kernel_timer(tx)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                stepx()
+            torch.cuda.synchronize()
+            dtx = (time.perf_counter() - t0) / 5
+            ops.set_kernel_timer(None)
+            line["exact_f32"] = {"dtype": DTYPE_EXACT, "steps": 5, "ms_per_step": round(dtx * 1e3, 4),
+                                 "value": round(n_rays / dtx, 1), "unit": "rays/s",
+                                 "kernels": {k: kernel_roofline(k, ms, n_samples, True)
+                                             for k, (ms, n) in tx.summary(median=True).items() if k in ALG}}
+            try:
+                line["secondary"] = secondary_workloads(device, inp)
+            except Exception as e:  # the headline must not depend on the extras
+                line["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -317,6 +317,13 @@ int tt_patch_composite_fwd(const float* low, const float* patch, float* out, int
 int tt_patch_composite_bwd(const float* g_out, float* g_low, float* g_patch, int32_t B, int32_t h, int32_t w, int32_t H,
                            int32_t W, int32_t C, int32_t PS, int32_t py, int32_t px, void* stream);
 
+/* Eikonal regulariser of the training loop on the renderer's per-sample `sdf_grad` output (n,3):
+ *   loss[0] = mean((||sdf_grad||_2 - 1)^2)      (multiprompt_dual_renderer_multistep_generator.py:696-699)
+ * one pass each way instead of ~10 torch kernels over the per-sample tensor.  _fwd overwrites loss[0] (device);
+ * _bwd: g_sdf_grad (n,3) = g_loss[0] * 2 (||g|| - 1) / (n ||g||) * g (0 where ||g|| = 0), g_loss a DEVICE scalar. */
+int tt_eikonal_fwd(const float* sdf_grad, int64_t n, float* loss, void* stream);
+int tt_eikonal_bwd(const float* sdf_grad, const float* g_loss, int64_t n, float* g_sdf_grad, void* stream);
+
 /* The renderer's per-ray composite (generative_space_sdf_volume_renderer.py:433-530) as one kernel each way:
  *   comp_rgb = rgb_fg + bg (1 - opacity)                                   bg: (3) with bg_stride 0, or (n,3) with 3
  *   disparity = clamp((far - (depth opacity + (1 - opacity) far)) / (far - near), 0, 1), far/near = d_cam +- sqrt(3)

@@ -1,0 +1,160 @@
+"""The N > 1 path on the GPU: two ranks on the ONE leased MI355X.
+
+  * test_two_ranks_*: each rank renders its contiguous shard of a 4-prompt batch with the HIP kernels, the six MLP
+    gradients live in a FlatGradBucket and are averaged with ONE all-reduce on the compute stream; checked against the
+    unsharded single-process batch (MLP gradients: sum over the batch / world; plane gradients: the rank's slice).
+    Backend "nccl" (= RCCL) first; RCCL may refuse two ranks on one device ("Duplicate GPU detected") -- then the
+    same job runs over gloo (CUDA tensors, so the kernels, the bucket and the sharding are still exercised on the GPU)
+    and the test is reported as skipped with RCCL's message.
+  * test_bench_spawns_its_own_ranks: `python bench.py --gpus 2` WITHOUT a launcher must run 2 ranks and say n_gpus = 2
+    (reference: Lightning DDP, configs/TriplaneTurbo_v1.yaml:255, launch.py:230-237)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(P=4, R=32, Hh=12, Ww=12, S=24):
+    from triplaneturbo_amd import synthetic as O
+    g = torch.Generator().manual_seed(5)
+    cache = torch.randn(P, 6, 32, R, R, generator=g) * 0.5
+    sw = O.init_mlp_weights([32, 64, 64, 1], g)
+    fw = O.init_mlp_weights([96, 64, 64, 3], g)
+    ro, rd, c2w, cd = O.make_cameras(P, Hh, Ww, azimuth_start_deg=20.0)
+    ts, te = O.uniform_intervals(P * Hh * Ww, S, 0.3, 3.2)
+    proj = torch.randn(P, Hh, Ww, 3, generator=g)
+    return cache, sw, fw, ro, rd, c2w, cd, ts, te, proj
+
+
+def _grads(sel, dist=None):
+    """forward + backward of prompts `sel` on cuda:0; MLP gradients through a FlatGradBucket (+ all-reduce)."""
+    from triplaneturbo_amd import functional, ops
+    from triplaneturbo_amd.parallel import FlatGradBucket
+    cache, sw, fw, ro, rd, c2w, cd, ts, te, proj = _batch()
+    dev = torch.device("cuda", 0)
+    Hh, Ww = ro.shape[1:3]
+    rays = Hh * Ww
+    idx = torch.tensor(list(sel))
+    ridx = (idx[:, None] * rays + torch.arange(rays)[None, :]).reshape(-1)
+    c = cache[idx].to(dev).requires_grad_(True)
+    sws = [w.to(dev).requires_grad_(True) for w in sw]
+    fws = [w.to(dev).requires_grad_(True) for w in fw]
+    bucket = FlatGradBucket(sws + fws)
+    bucket.zero_()
+    out = functional.volume_render(c, sws, fws, ro[idx].to(dev), rd[idx].to(dev), ts[ridx].to(dev), te[ridx].to(dev),
+                                   torch.ones(3, device=dev), cd[idx].to(dev), c2w[idx].to(dev), ops.RenderConfig(),
+                                   training=True)
+    # sums (not means): the loss of a batch is the sum of the losses of its shards
+    loss = (out["comp_rgb"] * proj[idx].to(dev)).sum() + out["opacity"].sum() + \
+        ((out["sdf_grad"].norm(dim=-1) - 1) ** 2).sum()
+    loss.backward()
+    bucket.all_reduce(dist, average=True)
+    torch.cuda.synchronize()
+    return c.grad.cpu(), bucket.flat_grad.cpu().clone()
+
+
+def _worker(rank, world, port, backend, q):
+    try:
+        import torch.distributed as dist
+        from triplaneturbo_amd.parallel import shard_prompts
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        sel = list(shard_prompts(4, rank, world))
+        g_planes, flat = _grads(sel, dist)
+        q.put((rank, "ok", sel, g_planes.numpy(), flat.numpy()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # reported to the parent instead of a silent non-zero exit
+        q.put((rank, "error", repr(e)[:600], None, None))
+
+
+def _run(backend, timeout=240):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(2):
+            res.append(q.get(timeout=timeout))
+    except Exception:
+        res.append((None, "error", f"timeout after {timeout} s", None, None))
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()  # (the exact child we started)
+    return res
+
+
+def test_two_ranks_share_the_gpu_one_flat_allreduce():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from parity import report
+    full_planes, full_flat = _grads(range(4))  # single process, whole batch (no dist: all_reduce is a no-op)
+    refused = None
+    res = _run("nccl")
+    if any(r[1] != "ok" for r in res):
+        refused = "; ".join(str(r[2]) for r in res if r[1] != "ok")
+        res = _run("gloo")
+    assert all(r[1] == "ok" for r in res), res
+    res = sorted(res, key=lambda r: r[0])
+    flats = [torch.from_numpy(r[4]) for r in res]
+    assert torch.equal(flats[0], flats[1])  # both ranks hold the same averaged gradients
+    # averaged over 2 ranks == the whole-batch sum / 2 (float-atomic summation order inside a rank: 1e-5)
+    rel = ((flats[0].double() - full_flat.double() / 2).norm() / (full_flat.double() / 2).norm()).item()
+    assert rel < 2e-5, rel
+    for r in res:  # plane gradients stay local: the rank's slice of the whole-batch gradient
+        got, want = torch.from_numpy(r[3]).double(), full_planes[torch.tensor(r[2])].double()
+        assert ((got - want).norm() / want.norm()).item() < 2e-5
+    report("two ranks on one GPU", {"backend": "gloo (RCCL refused device sharing)" if refused else "nccl (RCCL)",
+                                    "mlp_grad_rel_err": rel, "rccl_message": refused})
+    if refused:
+        pytest.skip(f"RCCL refuses two ranks on one device ({refused[:200]}); the same 2-rank job PASSED over gloo with "
+                    f"CUDA tensors (sharding, HIP kernels, flat bucket, averaged gradients verified on the GPU)")
+
+
+def test_bench_spawns_its_own_ranks():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    note = None
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:  # RCCL refuses two ranks on the one leased GPU: same path over gloo
+        note = (r.stderr or "")[-300:]
+        r = subprocess.run(cmd, env=dict(env, TT_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stderr[-2000:])
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2"
+    mg = d["multi_gpu"]
+    assert len(mg["per_rank_ms_per_step"]) == 2 and mg["rccl"]["world_size"] == 2 and mg["allreduce_bytes"] == 16640 * 4
+    assert d["value"] > 0 and abs(d["value"] - 2 * 65536 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_dp2_one_gpu.json"), "w") as f:
+        f.write(json.dumps(dict(d, note="2 ranks sharing ONE MI355X (pytest -m gpu); backend "
+                                        + mg["rccl"]["backend"] + ("; RCCL said: " + note if note else ""))) + "\n")

@@ -28,7 +28,7 @@ SYMBOLS = [
     "tt_march_fwd", "tt_march_bwd", "tt_sample_uniform", "tt_sample_importance",
     "tt_points_bwd_geo", "tt_points_bwd_tex", "tt_points_bwd_x", "tt_hashgrid_n_params", "tt_hashgrid_fwd", "tt_hashgrid_bwd",
     "tt_debug_poison_queue", "tt_patch_composite_fwd", "tt_patch_composite_bwd", "tt_render_eval",
-    "tt_composite_fwd", "tt_composite_bwd",
+    "tt_composite_fwd", "tt_composite_bwd", "tt_eikonal_fwd", "tt_eikonal_bwd",
 ]
 
 
@@ -160,6 +160,8 @@ def load() -> ctypes.CDLL:
         "tt_composite_fwd": [_P, _P, _P, _P, _P, _I32, _P, _P, _I64, _I32, _I32, _I32] + [_P] * 6,
         "tt_composite_bwd": [_P, _P, _P, _P, _P, _I32, _P, _P, _I64, _I32, _I32, _I32] + [_P] * 11,
         "tt_render_eval": [_P, _wp, _P, _P, _P, _P, _cfgp, _F, _F] + [_P] * 7,
+        "tt_eikonal_fwd": [_P, _I64, _P, _P],
+        "tt_eikonal_bwd": [_P, _P, _I64, _P, _P],
         "tt_patch_composite_fwd": [_P, _P, _P] + [_I32] * 9 + [_P],
         "tt_patch_composite_bwd": [_P, _P, _P] + [_I32] * 9 + [_P],
     }

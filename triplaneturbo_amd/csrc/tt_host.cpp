@@ -29,19 +29,26 @@ int tt_num_cus() {
 
 namespace {
 // Work-queue counter slots: 64 B each (8 per-XCD heads + padding: one cache line).
-//   * eager launches: ONE slot per (device, stream).  Launches on a stream are ordered, and every launch first
-//     enqueues a one-wave kernel that zeroes its slot on that stream, so a slot is clean whatever happened to the
-//     previous kernel that used it (fault, kill) and two launches that may run concurrently (different streams)
-//     never share counters.
-//   * launches recorded during a stream capture: a slot of their own from a second pool, never handed out again (a
-//     graph may be replayed on any stream, concurrently with eager launches on the capture stream); the zeroing
-//     kernel is captured as a node in front of the kernel node.
-constexpr int kMaxDevices = 64, kStreamSlots = 64, kGraphSlots = 4096, kSlotInts = 16;
+//   * eager launches: a RING of kRing slots per (device, stream).  Launches on a stream are ordered and every launch
+//     first enqueues a one-wave kernel that zeroes ITS slot on that stream, so a slot is clean whatever happened to the
+//     previous kernel that used it (fault, kill), two launches that may run concurrently (different streams) never
+//     share counters, and two host threads that enqueue on the SAME stream at the same time (ctypes releases the GIL)
+//     get different slots: the interleaving zero(A) zero(B) K1(A) K2(B) is harmless, where a single slot per stream
+//     would let K2 start on counters K1 has already advanced.
+//   * launches recorded during a stream capture: slots of a second pool handed out round-robin; the zeroing kernel is
+//     captured as a node in front of the kernel node, so a slot may be handed out again after kGraphSlots captured
+//     launches (a process that re-captures its graphs per shape / per epoch never runs out).  Not supported: more than
+//     kGraphSlots captured launches alive in graphs that replay CONCURRENTLY, and more than kStreams streams with
+//     launches in flight at once (the oldest stream entry is recycled, without a device-wide synchronisation -- which
+//     would be illegal while another stream is capturing).
+constexpr int kMaxDevices = 64, kStreams = 256, kRing = 4, kGraphSlots = 4096, kSlotInts = 16;
 struct DeviceScratch {
-    int* base = nullptr;                 // (kStreamSlots + kGraphSlots) * kSlotInts ints
-    hipStream_t streams[kStreamSlots];   // stream owning eager slot i
+    int* base = nullptr;             // (kStreams * kRing + kGraphSlots) * kSlotInts ints
+    hipStream_t streams[kStreams];   // stream owning eager ring i
+    unsigned next[kStreams];         // next ring position of stream i
     int n_streams = 0;
-    int n_graph = 0;
+    int evict = 0;                   // next stream entry to recycle once the table is full
+    unsigned n_graph = 0;
 };
 DeviceScratch g_scratch[kMaxDevices];
 std::mutex g_scratch_mu;
@@ -61,28 +68,26 @@ int* tt_queue_counters(hipStream_t stream) {
         if (!d.base) {
             if (cap != hipStreamCaptureStatusNone) return nullptr;  // first use must not be inside a capture
             void* ptr = nullptr;
-            if (hipMalloc(&ptr, (size_t)(kStreamSlots + kGraphSlots) * kSlotInts * sizeof(int)) != hipSuccess)
+            if (hipMalloc(&ptr, (size_t)(kStreams * kRing + kGraphSlots) * kSlotInts * sizeof(int)) != hipSuccess)
                 return nullptr;
             d.base = static_cast<int*>(ptr);
         }
         if (cap != hipStreamCaptureStatusNone) {
-            if (d.n_graph >= kGraphSlots) return nullptr;
-            slot = d.base + (size_t)(kStreamSlots + d.n_graph++) * kSlotInts;
+            slot = d.base + (size_t)(kStreams * kRing + (d.n_graph++ % kGraphSlots)) * kSlotInts;
         } else {
             int k = 0;
             while (k < d.n_streams && d.streams[k] != stream) ++k;
             if (k == d.n_streams) {
-                if (d.n_streams == kStreamSlots) {
-                    // more distinct streams than slots (stream handles come and go): once the device is idle no
-                    // slot is in use, so the table starts over
-                    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-                    d.n_streams = 0;
-                    k = 0;
+                if (d.n_streams == kStreams) {  // stream handles come and go: recycle the oldest entry
+                    k = d.evict;
+                    d.evict = (d.evict + 1) % kStreams;
+                } else {
+                    ++d.n_streams;
                 }
-                ++d.n_streams;
                 d.streams[k] = stream;
+                d.next[k] = 0;
             }
-            slot = d.base + (size_t)k * kSlotInts;
+            slot = d.base + (size_t)(k * kRing + (d.next[k]++ % kRing)) * kSlotInts;
         }
     }
     // zeroed by a one-wave KERNEL, not hipMemsetAsync: as a graph node the 64-byte memset was not reliably re-executed
@@ -93,12 +98,14 @@ int* tt_queue_counters(hipStream_t stream) {
     return slot;
 }
 
-// Test hook (tests/test_gpu_graph.py): fills the work-queue slot the next eager launch on `stream` will use with
-// garbage, as a faulted or killed kernel would leave it.  The launch must still pop every item, because
-// tt_queue_counters zeroes the slot on the stream in front of every launch.
+// Test hook (tests/test_gpu_graph.py): fills every work-queue slot of `stream`'s ring (so also the one the next eager
+// launch on it will use) with garbage, as a faulted or killed kernel would leave it.  The launch must still pop every
+// item, because tt_queue_counters zeroes the slot on the stream in front of every launch.
 extern "C" int tt_debug_poison_queue(void* stream) {
-    int* slot = tt_queue_counters((hipStream_t)stream);
-    if (!slot) return TT_ERR_DEVICE;
-    return hipMemsetAsync(slot, 0x7f, kSlotInts * sizeof(int), (hipStream_t)stream) == hipSuccess ? TT_OK
-                                                                                                 : TT_ERR_DEVICE;
+    for (int r = 0; r < kRing; ++r) {
+        int* slot = tt_queue_counters((hipStream_t)stream);
+        if (!slot) return TT_ERR_DEVICE;
+        if (hipMemsetAsync(slot, 0x7f, kSlotInts * sizeof(int), (hipStream_t)stream) != hipSuccess) return TT_ERR_DEVICE;
+    }
+    return TT_OK;
 }

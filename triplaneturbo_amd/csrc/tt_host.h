@@ -17,8 +17,8 @@ struct TileGeom;
 long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g, int default_order);
 
 // Work-queue counters for one kernel launch: 8 int32 heads (one per XCD) in a library-owned device scratch, zeroed on
-// `stream` by a one-wave kernel enqueued here (so the caller must launch the kernel on the same stream, next).  One
-// slot per (device, stream) for eager launches, a fresh never-reused slot per launch recorded under stream capture
-// (see tt_host.cpp).  Returns nullptr on a HIP error.  (The only state the library keeps: a 266 KB allocation per
+// `stream` by a one-wave kernel enqueued here (so the caller must launch the kernel on the same stream, next).  A
+// ring of slots per (device, stream) for eager launches, a round-robin pool for launches recorded under stream capture
+// (see tt_host.cpp).  Returns nullptr on a HIP error.  (The only state the library keeps: a 328 KB allocation per
 // device, never freed; its first use must not happen inside a stream capture.)
 int* tt_queue_counters(hipStream_t stream);

@@ -510,6 +510,17 @@ def march_backward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, fwd: di
     return out
 
 
+def _zeros_like_flat(tensors: Sequence[Tensor]) -> List[Tensor]:
+    """zeros_like for a list of tensors as views of one buffer (one fill kernel instead of one per tensor)"""
+    sizes = [t.numel() for t in tensors]
+    flat = torch.zeros(sum(sizes), device=tensors[0].device, dtype=tensors[0].dtype)
+    out, ofs = [], 0
+    for t, n in zip(tensors, sizes):
+        out.append(flat[ofs:ofs + n].view_as(t))
+        ofs += n
+    return out
+
+
 def _grads_struct(tensors: Sequence[Tensor]):
     return _lib.MlpWeights(*[_ptr(t) for t in tensors])  # same layout as tt_mlp_grads (6 pointers)
 
@@ -547,7 +558,7 @@ class _TriplaneRenderFn(torch.autograd.Function):
         wst, keep = _weights_struct((w1, w2, w3), (v1, v2, v3))
         copies = max(1, int(ctx.rc.grad_copies))
         grad_packed = torch.zeros((copies,) + tuple(packed.shape), device=packed.device, dtype=torch.float32)
-        gw = [torch.zeros_like(t) for t in (w1, w2, w3, v1, v2, v3)]
+        gw = _zeros_like_flat((w1, w2, w3, v1, v2, v3))  # six views of ONE zero-filled buffer: one fill launch
         gst = _grads_struct(gw)
 
         def c(t):
@@ -741,3 +752,33 @@ def composite(opacity: Tensor, depth: Tensor, rgb_fg: Tensor, normal_acc: Tensor
     rgb, disp, cn, vis, visw = _CompositeFn.apply(opacity, depth, rgb_fg, normal_acc, bg_color, camera_distances, c2w,
                                                   int(rays_per_view), mode, int(view_group))
     return rgb, disp, cn, (vis if mode == 1 else None), (visw if mode != 0 else None)
+
+
+class _EikonalFn(torch.autograd.Function):
+    """tt_eikonal_fwd / _bwd: mean((||sdf_grad|| - 1)^2) in one pass each way."""
+
+    @staticmethod
+    def forward(ctx, sdf_grad):
+        g = _chk(sdf_grad, "sdf_grad")
+        if g.ndim != 2 or g.shape[1] != 3:
+            raise ValueError(f"sdf_grad must be (n, 3), got {tuple(g.shape)}")
+        loss = torch.empty((), device=g.device, dtype=torch.float32)
+        _lib.check(_lib.load().tt_eikonal_fwd(_ptr(g), g.shape[0], _ptr(loss), _stream()), "tt_eikonal_fwd")
+        ctx.save_for_backward(g)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss):
+        g, = ctx.saved_tensors
+        out = torch.empty_like(g)
+        g_loss = g_loss.contiguous().float()
+        _lib.check(_lib.load().tt_eikonal_bwd(_ptr(g), _ptr(g_loss), g.shape[0], _ptr(out), _stream()), "tt_eikonal_bwd")
+        return out
+
+
+def eikonal_loss(sdf_grad: Tensor) -> Tensor:
+    """mean((||sdf_grad||_2 - 1)^2) over the samples (the training loop's eikonal regulariser,
+    multiprompt_dual_renderer_multistep_generator.py:696-699) as one HIP kernel each way; sdf_grad (n,3) is the
+    renderer's `out["sdf_grad"]`.  Equal to `((torch.linalg.norm(g, ord=2, dim=-1) - 1.0) ** 2).mean()`."""
+    return _EikonalFn.apply(sdf_grad)
