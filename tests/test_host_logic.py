@@ -250,3 +250,23 @@ def test_geometry_decode_applies_split_channels_v1():
     y = g.decode(x)
     assert y.shape == (2, 6, 32, 4, 4)
     assert torch.equal(y[:, :3], x[:, :3, :32]) and torch.equal(y[:, 3:], x[:, 3:, 32:])
+
+
+def test_no_kernel_selects_on_a_scalar_alu_combination_of_fresh_compare_masks(tmp_path):
+    """Mechanical guard of DESIGN.md section 6 (stale lane-mask bits after v_cmp -> s_and_b64 / s_or_b64 -> v_cndmask):
+    tools/mask_hazard_lint.py disassembles the device code of the PRODUCT library and must find no such sequence in any
+    kernel (window of 4 instructions behind the combination, masks at most 16 instructions old) -- and it must FLAG the
+    negative control, the textbook in-bounds logic `in = bx && by; w = in ? wx * wy : 0` that corners_setup replaced
+    (tools/mask_hazard_probe.hip), so a revert of the 0/1-factor convention (csrc/tt_mask.h) cannot pass silently."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import mask_hazard_lint as L
+    if not os.path.exists(L.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    found = L.lint(_lib.build(), window=4, fresh=16)
+    assert not found, {k: v[:2] for k, v in found.items()}
+    probe = tmp_path / "probe.so"
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-shared", "-fPIC",
+                    "-fno-gpu-rdc", os.path.join(ROOT, "tools", "mask_hazard_probe.hip"), "-o", str(probe)], check=True,
+                   cwd=str(tmp_path))
+    flagged = L.lint(str(probe), window=4, fresh=16)
+    assert any("k_textbook_corners" in k for k in flagged), flagged

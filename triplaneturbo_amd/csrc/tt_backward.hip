@@ -235,16 +235,19 @@ __device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M
     const int old1 = atomicCAS(a1 ? tg + r.h1 : dummy, -1, r.o1);
     s.m0 = old0 == -1;
     s.m1 = old1 == -1;
-    s.w0 = s.m0 || old0 == r.o0;
-    s.w1 = s.m1 || old1 == r.o1;
-    s.l0 = a0 && !s.w0;
-    s.l1 = a1 && !s.w1;
+    s.w0 = tt_eq_either(old0, -1, r.o0);  // won the slot, or it already holds this texel (one compare: tt_device.h)
+    s.w1 = tt_eq_either(old1, -1, r.o1);
+    // not written to M.  (An inactive reference CASes the dummy tag -2, so it is "not written" too; what makes a
+    // reference LOST is a non-zero coefficient on top -- scatter_lost tests the coefficient it selects with this flag,
+    // instead of combining two lane masks here.)
+    s.l0 = !s.w0;
+    s.l1 = !s.w1;
     m_store<EXACT>(M, s.w0 ? r.h0 : 64, i, r.c0);
     m_store<EXACT>(M, s.w1 ? r.h1 : 64, i, r.c1);
 #ifdef TT_TUNING
     if (st) {  // wave-uniform values, flushed once per wave with the phase timers
         st[0] += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
-        st[1] += __popcll(__ballot(s.l0)) + __popcll(__ballot(s.l1));
+        st[1] += __popcll(__ballot((s.l0 ? r.c0 : 0.f) != 0.f)) + __popcll(__ballot((s.l1 ? r.c1 : 0.f) != 0.f));
         st[2] += 1;
     }
 #endif
@@ -255,12 +258,13 @@ __device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M
 // memory, one half-wave per reference (lanes <-> channels: a coalesced 128-byte atomic each)
 __device__ __forceinline__ void scatter_lost(const PlaneRefs& r, const ClaimState& s, const float* Qs, float* Ls,
                                              __amdgpu_buffer_rsrc_t grsrc, int i, int hi) {
-    const unsigned long long bal = __ballot(s.l0 || s.l1);
+    const float lc0 = s.l0 ? r.c0 : 0.f, lc1 = s.l1 ? r.c1 : 0.f;  // coefficient of a lost corner, else 0
+    const unsigned long long bal = __ballot(__builtin_fabsf(lc0) + __builtin_fabsf(lc1) != 0.f);
     if (bal == 0) return;
     float* Lc = Ls;                                 // [sample][4] coefficient of a lost corner, else 0
     int* Lo = reinterpret_cast<int*>(Ls + 32 * 4);  // [sample][4] absolute texel index
-    Lc[4 * i + 2 * hi] = s.l0 ? r.c0 : 0.f;
-    Lc[4 * i + 2 * hi + 1] = s.l1 ? r.c1 : 0.f;
+    Lc[4 * i + 2 * hi] = lc0;
+    Lc[4 * i + 2 * hi + 1] = lc1;
     Lo[4 * i + 2 * hi] = r.o0;
     Lo[4 * i + 2 * hi + 1] = r.o1;
     // walk only the samples that lost something, two per step (one per half-wave)
@@ -503,6 +507,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         if (b >= tg.n_blocks) continue;  // padding of the ragged last deal round
         bool ray_ok;
         const long long ray = tile_ray(tg, b, i, ray_ok);
+        const float ray_okf = tt_opaque(ray_ok ? 1.f : 0.f);  // 0/1 factor the compiler cannot fold back into a mask
         const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
         const int view = (int)(ray / cfg.rays_per_view);
         const size_t pofs = (size_t)(view / cfg.views_per_prompt) * plane_stride;
@@ -534,10 +539,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             const bool rvalid = ray_ok && si < s_end;
             // validity as a 0/1 FACTOR built from single compares (x * 1 = x, finite * 0 = 0): no select on a lane mask
             // that the scalar ALU has just combined (see corners_setup in tt_device.h)
-            const float vf = (ray_ok ? 1.f : 0.f) * (si < s_end ? 1.f : 0.f);
+            const float vf = ray_okf * (si < s_end ? 1.f : 0.f);
             const float sbar = in.up[0] * vf, gbx = in.up[1] * vf, gby = in.up[2] * vf, gbz = in.up[3] * vf;
             TT_PHASE(0);
-            if (!__any(sbar != 0.f || gbx != 0.f || gby != 0.f || gbz != 0.f)) continue;  // exact
+            if (!__any(tt_any_nonzero4(sbar, gbx, gby, gbz))) continue;  // exact
             float tm, px, py, pz;
             sample_position(ox, oy, oz, dx, dy, dz, in.ts, in.te, tm, px, py, pz);
             const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius),
@@ -733,6 +738,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         if (b >= tg.n_blocks) continue;  // padding of the ragged last deal round
       bool ray_ok;
       const long long ray = tile_ray(tg, b, i, ray_ok);
+      const float ray_okf = tt_opaque(ray_ok ? 1.f : 0.f);  // 0/1 factor the compiler cannot fold back into a mask
       const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
       const int view = (int)(ray / cfg.rays_per_view);
       const size_t pofs = (size_t)(view / cfg.views_per_prompt) * plane_stride;
@@ -771,7 +777,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         in_next = load_step(sb0 + tg.sb);
         const int si = sb0 + ks;
         const bool valid = ray_ok && si < s_end;
-        const float vf = (ray_ok ? 1.f : 0.f) * (si < s_end ? 1.f : 0.f);
+        const float vf = ray_okf * (si < s_end ? 1.f : 0.f);
         // ---- upstream: cbar_o = shrink * w_i * g_rgb[ray,o] * 1.002 * s(1-s) + g_features ----
         float cb[3];
 #pragma unroll
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             cb[o] = c * vf;  // 0/1 factor, not a select on a freshly combined lane mask (see k_decode_bwd_geo)
         }
         TT_PHASE(0);
-        if (!__any(cb[0] != 0.f || cb[1] != 0.f || cb[2] != 0.f)) continue;  // exact: nothing flows back
+        if (!__any(tt_any_nonzero3(cb[0], cb[1], cb[2]))) continue;  // exact: nothing flows back
 #ifdef TT_TUNING
         {  // live-lane statistics (tools/phase_cycles.py): slots 12 / 13 are unused by the timers
             const unsigned long long live = __ballot(cb[0] != 0.f || cb[1] != 0.f || cb[2] != 0.f) & 0xffffffffull;

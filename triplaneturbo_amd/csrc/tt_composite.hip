@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "tt_host.h"
+#include "tt_mask.h"
 
 struct PatchParams {
     const float* low;    // (B, h, w, C)
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(CompositeBwdParams q) {
             const float far = p.cam_dist[v] + 1.7320508075688772f, near = p.cam_dist[v] - 1.7320508075688772f;
             const float tmp = dep * op + (1.f - op) * far;
             const float raw = (far - tmp) / (far - near);
-            const float inside = (raw >= 0.f ? 1.f : 0.f) * (raw <= 1.f ? 1.f : 0.f);  // clip gradient as a 0/1 factor
+            const float inside = tt_opaque(raw >= 0.f ? 1.f : 0.f) * (raw <= 1.f ? 1.f : 0.f);  // clip gradient: 0/1 factor
             const float g = inside * (-q.g_disparity[e] / (far - near));  // d / d tmp
             g_dep += g * op;
             g_op += g * (dep - far);

@@ -44,6 +44,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LIDX(r, hi) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hi))
 
+#include "tt_mask.h"
+
 // ---- LDS image of the MLP weights: row-major, row stride = cols + 4 floats -----------------------
 // (+4 keeps 16-byte alignment and makes the per-lane-row ds_read_b128 of mv_fwd conflict-free:
 //  36*i, 68*i, 100*i mod 64 hit 16 distinct 4-bank slots for the 16 lanes of a b128 lane group.)
@@ -202,6 +204,10 @@ struct Corners {
 // or without s_nops; isolated sequences in tools/sgpr_hazard_probe.hip do not reproduce it).  Here every flag is a float 0/1 made by ONE compare + select (VALU -> VALU through VCC, a hazard hipcc
 // handles) and combined by multiplication; results are bit-identical to the textbook form (x * 1 = x, finite * 0 = 0).
 __device__ __forceinline__ void corners_setup(float gx, float gy, int H, int W, bool valid, Corners& c) {
+    // a non-finite coordinate is out of bounds (ATen's within_bounds_2d is false for NaN: the sample contributes 0; with
+    // 0/1 factors NaN * 0 would be NaN): send it far outside, one compare + select per axis
+    gx = __builtin_fabsf(gx) < 1e30f ? gx : 4.f;
+    gy = __builtin_fabsf(gy) < 1e30f ? gy : 4.f;
     // same op order as the reference: ((coord + 1) * size - 1) / 2
     float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
     float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
@@ -771,20 +777,22 @@ struct TileGeom {
 __device__ __forceinline__ long long tile_ray(const TileGeom& g, long long b, int j, bool& rvalid) {
     // The returned index is ALWAYS a valid ray (clamped arithmetically, not selected on the validity mask): a lane
     // outside the image / past the last ray works on a duplicate whose contributions `rvalid` switches off.
+    // Validity is built from single compares as 0/1 factors and tested ONCE (lane-mask hygiene, tt_mask.h).
     long long ray;
+    float okf = 1.f;
     const int jr = j / g.sb;
     if (g.image_w > 0) {
         const long long view = b / g.bpv;
         const int rem = (int)(b - view * g.bpv);
         const int by = rem / g.bpr, bx = rem - by * g.bpr;
         const int x = bx * g.bw + (jr % g.bw), y = by * g.bh + (jr / g.bw);
-        rvalid = x < g.image_w && y < g.image_h;
+        okf = tt_opaque(x < g.image_w ? 1.f : 0.f) * (y < g.image_h ? 1.f : 0.f);
         ray = view * g.rays_per_view + (long long)min(y, g.image_h - 1) * g.image_w + min(x, g.image_w - 1);
     } else {
         ray = b * (32 / g.sb) + jr;
-        rvalid = true;
     }
-    rvalid = rvalid && ray < g.n_rays;
+    okf = tt_opaque(okf) * (ray < g.n_rays ? 1.f : 0.f);
+    rvalid = okf != 0.f;
     return ray < g.n_rays - 1 ? ray : g.n_rays - 1;
 }
 

@@ -482,6 +482,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
         if (b >= tg.n_blocks) continue;
         bool ray_ok;
         const long long ray = tile_ray(tg, b, i, ray_ok);
+        const float ray_okf = tt_opaque(ray_ok ? 1.f : 0.f);  // 0/1 factor (lane-mask hygiene, tt_device.h)
         const int view = (int)(ray / cfg.rays_per_view);
         DecodeCfg dc;
         dc.planes = p.packed;
@@ -503,7 +504,9 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
             float tm, px, py, pz;
             sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
             const float X = scale_coord(px, dc.radius), Y = scale_coord(py, dc.radius), Z = scale_coord(pz, dc.radius);
-            const bool live = ray_ok && !(T < p.eps_T);  // (eps_T = 0: always live)
+            // live = ray_ok && !(T < eps_T) as a product of 0/1 factors, then ONE compare (eps_T = 0: always live)
+            const float livef = ray_okf * (T < p.eps_T ? 0.f : 1.f);
+            const bool live = livef != 0.f;
             float s0, gq[3];
             decode_geo_fwd<true, EXACT>(L, dc, X, Y, Z, live, i, hi, s0, gq);
             ++n_geo;
@@ -514,6 +517,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
             const float ign = rcp_(gn);
             const float ux = gx * ign, uy = gy * ign, uz = gz * ign;
             const float cosv = dx * ux + dy * uy + dz * uz;
+            // (select, not a product: a dead lane's alpha may be NaN -- it decodes nothing)
             float alpha = neus_alpha_terms(sdf, cosv, te - ts, cfg.inv_std, cfg.cos_anneal_ratio).alpha;
             if (!live) alpha = 0.f;
             const float wgt = alpha * T;
@@ -524,7 +528,9 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
             nx = fmaf(wgt, ux, nx);
             ny = fmaf(wgt, uy, ny);
             nz = fmaf(wgt, uz, nz);
-            const bool want_tex = live && wgt > p.eps_w;  // (eps_w = 0: every sample with a non-zero weight)
+            // want_tex = live && wgt > eps_w: wgt = alpha T is exactly 0 on a dead lane (alpha = 0 above) and eps_w >= 0,
+            // so the weight test alone decides (eps_w = 0: every sample with a non-zero weight)
+            const bool want_tex = wgt > p.eps_w;
             if (__any(want_tex)) {
                 float c[3];
                 decode_tex_fwd<EXACT>(L, dc, X, Y, Z, want_tex, i, hi, c);
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
                     cb = fmaf(wgt, sigmoid_(c[2]) * 1.002f - 0.001f, cb);
                 }
             }
-            if (p.eps_T > 0.f && !__any(ray_ok && !(T < p.eps_T))) break;  // every ray of the tile is opaque
+            if (p.eps_T > 0.f && !__any(ray_okf * (T < p.eps_T ? 0.f : 1.f) != 0.f)) break;  // every ray is opaque
         }
         if (ray_ok && hi == 0) {
             p.opacity[ray] = op;

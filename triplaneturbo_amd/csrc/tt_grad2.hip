@@ -93,7 +93,8 @@ __device__ __forceinline__ Axis<A> axis_setup(A g, int size, int border, int ali
     }
     if (border) {
         const A hi = (A)(size - 1);
-        const A inside = (ip > 0 ? (A)1 : (A)0) * (ip < hi ? (A)1 : (A)0);
+        // (tt_opaque_t: otherwise the compiler folds the product of two 0/1 selects back into s_and_b64 + one select)
+        const A inside = tt_opaque_t<A>(ip > 0 ? (A)1 : (A)0) * (ip < hi ? (A)1 : (A)0);
         mult = mult * inside;
         ip = ip < 0 ? (A)0 : (ip > hi ? hi : ip);
     }

@@ -51,9 +51,14 @@ __device__ __forceinline__ void stage_image16(float* dst_f, const float* __restr
     unsigned* slot = reinterpret_cast<unsigned*>(dst_f + K);  // pad of row 0: max |entry| as bits, then the factor
     if (threadIdx.x == 0) *slot = 0u;
     __syncthreads();
-    float m = 0.f;
-    for (int e = threadIdx.x; e < ROWS * K; e += blockDim.x) m = fmaxf(m, __builtin_fabsf(src[e]));
-    atomicMax(slot, __builtin_bit_cast(unsigned, m));  // non-negative floats order like their bit patterns
+    // max |entry| on the BIT PATTERNS (non-negative floats order like their bit patterns): integer max only -- the float
+    // form made hipcc emit NaN-test masks combined on the scalar ALU in this loop (tools/mask_hazard_lint.py)
+    unsigned mb = 0u;
+    for (int e = threadIdx.x; e < ROWS * K; e += blockDim.x) {
+        const unsigned b = __builtin_bit_cast(unsigned, src[e]) & 0x7fffffffu;
+        mb = b > mb ? b : mb;
+    }
+    atomicMax(slot, mb);
     __syncthreads();
     int E = (int)(*slot >> 23);
     E = E < 16 ? 16 : (E > 240 ? 240 : E);

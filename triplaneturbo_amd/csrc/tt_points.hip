@@ -97,8 +97,8 @@ __global__ __launch_bounds__(256, 1) void k_points_bwd_x(PointsBwdXParams p) {
             gg[o] = p.g_sdf_grad ? p.g_sdf_grad[idx * 3 + o] * vf : 0.f;
             gf[o] = p.g_feat ? p.g_feat[idx * 3 + o] * vf : 0.f;
         }
-        const bool need_geo = __any(gs != 0.f || gg[0] != 0.f || gg[1] != 0.f || gg[2] != 0.f);
-        const bool need_tex = __any(gf[0] != 0.f || gf[1] != 0.f || gf[2] != 0.f);
+        const bool need_geo = __any(tt_any_nonzero4(gs, gg[0], gg[1], gg[2]));  // one compare each (tt_device.h)
+        const bool need_tex = __any(tt_any_nonzero3(gf[0], gf[1], gf[2]));
         float q[16], eb[48];
 #pragma unroll
         for (int r = 0; r < 16; ++r) q[r] = 0.f;
