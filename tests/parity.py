@@ -25,6 +25,10 @@ RTOL_ELEM = 1e-4
 ATOL_ELEM = 1e-6
 ELEM_SLACK = 1.5    # HIP may violate the element-wise bar vs fp64 on at most 1.5x the fp32 oracle's fraction ...
 ELEM_FLOOR = 2e-3   # ... + 0.2 % of the elements (float-atomic summation order)
+ELEM_VS_FP32 = 0.08  # and directly against the fp32 oracle at most 8 % of the elements may miss the bar (measured, round 3:
+#                      planes <= 0.1 %, weight matrices <= 5.7 % default path / <= 2.6 % exact-f32 path, worst element
+#                      <= 33x its allowance -- while the fp32 oracle misses the same bar against fp64 on 5 ... 97 % of the
+#                      elements with worst elements 100 ... 18 000x their allowance: profiles/r03_parity_report.jsonl)
 NAMES = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]
 
 
@@ -67,6 +71,7 @@ def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-
         if elem:
             assert r["elem_hip_vs_fp64"]["viol_frac"] <= ELEM_SLACK * r["elem_fp32_vs_fp64"]["viol_frac"] + ELEM_FLOOR, \
                 (case, n, r)
+            assert r["elem_hip_vs_fp32"]["viol_frac"] <= ELEM_VS_FP32, (case, n, r)
     return rows
 
 

@@ -158,3 +158,49 @@ def test_bench_spawns_its_own_ranks():
     with open(os.path.join(ROOT, "gpurun_out", "bench_dp2_one_gpu.json"), "w") as f:
         f.write(json.dumps(dict(d, note="2 ranks sharing ONE MI355X (pytest -m gpu); backend "
                                         + mg["rccl"]["backend"] + ("; RCCL said: " + note if note else ""))) + "\n")
+
+
+def _rccl_world1(q):
+    try:
+        import torch.distributed as dist
+        from triplaneturbo_amd.parallel import FlatGradBucket
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        params = [torch.randn(s, device="cuda", requires_grad=True) for s in ((64, 32), (64, 64), (1, 64), (64, 96),
+                                                                              (64, 64), (3, 64))]
+        bucket = FlatGradBucket(params)
+        bucket.flat_grad.copy_(torch.arange(bucket.flat_grad.numel(), device="cuda", dtype=torch.float32))
+        want = bucket.flat_grad.clone()
+        for _ in range(3):  # the collective the N > 1 path issues, on the compute stream, in place on the flat buffer
+            dist.all_reduce(bucket.flat_grad, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        ok = torch.equal(bucket.flat_grad, want) and torch.equal(params[1].grad.reshape(-1), want[2048:2048 + 4096])
+        q.put(("ok" if ok else "mismatch", dist.get_backend(), str(torch.cuda.nccl.version())))
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put(("error", repr(e)[:500], ""))
+
+
+def test_rccl_allreduce_executes_on_the_flat_bucket():
+    """RCCL itself, as far as one leased GPU allows: a 1-rank "nccl" (= RCCL) process group, communicator init on
+    cuda:0 and the in-place all-reduce of the 66.6 KB flat MLP-gradient buffer on the compute stream (the exact call of
+    FlatGradBucket.all_reduce; with one rank the sum is the identity).  Two ranks on one device are refused by RCCL
+    ("Duplicate GPU detected"), see the test above."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1, args=(q,))
+    p.start()
+    try:
+        status, backend, ver = q.get(timeout=240)
+    finally:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+    assert status == "ok", (status, backend)
+    assert backend == "nccl"
+    from parity import report
+    report("RCCL 1-rank all-reduce of the flat MLP-gradient bucket", {"backend": backend, "rccl_version": ver})
