@@ -371,6 +371,8 @@ def main():
                     help="1 = BASELINE configs[1] per GPU (headline); 3 = configs[3]: 8 prompts x 256x256 rays per GPU")
     ap.add_argument("--exact-f32", action="store_true",
                     help="A/B: every matrix product on the fp32-input MFMA (TT_R_EXACT_F32) instead of split-fp16")
+    ap.add_argument("--wgrad-f32", action="store_true",
+                    help="A/B: weight-gradient outer products on the fp32 MFMA (TT_R_WGRAD_F32) instead of split-fp16")
     ap.add_argument("--torch-loss", action="store_true",
                     help="A/B: the eikonal term of the G6 loss with plain torch ops instead of ops.eikonal_loss")
     ap.add_argument("--graph", action="store_true",
@@ -379,6 +381,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-f32 sub-result and the secondary workloads")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # body of a rocprofv3 pass: steps only
+    ap.add_argument("--lib-variant", default=None, help=argparse.SUPPRESS)  # dev A/B: an experiment build of the library
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
@@ -408,7 +411,9 @@ def main():
             dist.init_process_group(backend)
 
     from triplaneturbo_amd import _lib
-    if local_rank == 0:
+    if args.lib_variant:
+        _lib.use_variant(args.lib_variant)
+    elif local_rank == 0:
         _lib.build()  # in-tree hipcc build; no-op when libtt_hip.so is up to date
     if world > 1:
         dist.barrier()
@@ -418,7 +423,7 @@ def main():
     R, Hh, Ww, S = 256, 256, 256, 128
     inp = make_inputs(rank, world, device, args.config, R, Hh, Ww, S)
     P = inp["cache"].shape[0]
-    rc = ops.RenderConfig(exact_f32=args.exact_f32)
+    rc = ops.RenderConfig(exact_f32=args.exact_f32, wgrad_f32=args.wgrad_f32)
     bucket = FlatGradBucket(inp["sw"] + inp["fw"])  # MLP grads = views of one buffer: one collective, no cat / copies
     fused = not args.torch_loss
 

@@ -129,6 +129,9 @@ typedef struct {
                              chain) instead of the default 2-term split-fp16 products (22-bit significands, fp32
                              accumulation, ~5x less matrix-pipe time): the A/B reference of that scheme, and an opt-out */
 
+#define TT_R_WGRAD_F32 4  /* backward: weight-gradient outer products on the fp32-input MFMA (implied by TT_R_EXACT_F32)
+                             instead of the default split-fp16 products with per-launch operand scales; A/B switch */
+
 /* tt_query_points / tt_query_field / tt_decode_rays / tt_points_bwd_* flags */
 #define TT_Q_NORMAL 1    /* output sdf_grad (analytic normal path) */
 #define TT_Q_TEX 2       /* output features (texture planes + feature net) */

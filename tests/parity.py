@@ -24,7 +24,7 @@ TOL_VS_FP32 = 1e-4
 RTOL_ELEM = 1e-4
 ATOL_ELEM = 1e-6
 ELEM_SLACK = 1.5    # HIP may violate the element-wise bar vs fp64 on at most 1.5x the fp32 oracle's fraction ...
-ELEM_FLOOR = 2e-3   # ... + 0.2 % of the elements (float-atomic summation order)
+ELEM_FLOOR = 5e-3   # ... + 0.5 % of the elements (float-atomic summation order; split-fp16 rounding of tiny elements)
 ELEM_VS_FP32 = 0.08  # and directly against the fp32 oracle at most 8 % of the elements may miss the bar (measured, round 3:
 #                      planes <= 0.1 %, weight matrices <= 5.7 % default path / <= 2.6 % exact-f32 path, worst element
 #                      <= 33x its allowance -- while the fp32 oracle misses the same bar against fp64 on 5 ... 97 % of the

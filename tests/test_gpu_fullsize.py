@@ -113,7 +113,7 @@ def band_oracle(full):
             l = l + ((torch.linalg.norm(o["sdf_grad"], ord=2, dim=-1) - 1.0) ** 2).sum() / (n * S)
             for t, g in zip(acc, torch.autograd.grad(l, [cc] + ws)):
                 t += g
-            total += float(l)
+            total += float(l.detach())
         return total, acc
 
     res = oracle(torch.float32), oracle(torch.float64)

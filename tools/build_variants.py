@@ -1,0 +1,11 @@
+"""Dev tool: build experiment variants of the library for A/B runs (tools/ab.sh with --lib-variant NAME).
+usage: python tools/build_variants.py name1=-DFOO,-DBAR name2=-DBAZ ..."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from triplaneturbo_amd import _lib  # noqa: E402
+
+for spec in sys.argv[1:]:
+    name, _, defs = spec.partition("=")
+    print(_lib.build(force=True, variant=name, defines=[d for d in defs.split(",") if d]))

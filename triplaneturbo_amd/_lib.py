@@ -45,16 +45,20 @@ def needs_build(path: str = LIB_PATH) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tuning: bool = False, variant: Optional[str] = None,
+          defines: Optional[List[str]] = None) -> str:
     """hipcc --offload-arch=gfx950 ... -shared -> triplaneturbo_amd/libtt_hip.so (in-tree).  One hipcc process per
-    translation unit, in parallel, then a link.  tuning=True builds the dev variant libtt_hip_tuning.so instead."""
+    translation unit, in parallel, then a link.  tuning=True builds the dev variant libtt_hip_tuning.so instead;
+    variant="x" + defines=["-DFOO"] builds an experiment library libtt_hip_x.so (dev A/B runs, tools/ab.sh)."""
     out = TUNING_LIB_PATH if tuning else LIB_PATH
+    if variant:
+        out = os.path.join(_HERE, f"libtt_hip_{variant}.so")
     if not force and not needs_build(out):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(_HERE, "build", "tuning" if tuning else "release")
+    objdir = os.path.join(_HERE, "build", variant or ("tuning" if tuning else "release"))
     os.makedirs(objdir, exist_ok=True)
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DTT_TUNING"] if tuning else [])
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DTT_TUNING"] if tuning else []) + list(defines or [])
     procs = []
     for s in _sources():
         obj = os.path.join(objdir, os.path.basename(s) + ".o")
@@ -82,6 +86,17 @@ def use_tuning_build() -> None:
     if _lib is not None:
         raise RuntimeError("use_tuning_build() must be called before the library is first loaded")
     LIB_PATH = build(tuning=True)
+
+
+def use_variant(name: str) -> None:
+    """Dev tools only: bind an experiment library built by build(variant=name, defines=[...]) (must exist already)."""
+    global _lib, LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_variant() must be called before the library is first loaded")
+    path = os.path.join(_HERE, f"libtt_hip_{name}.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is not built")
+    LIB_PATH = path
 
 
 _lib: Optional[ctypes.CDLL] = None
@@ -112,6 +127,7 @@ class HashGridCfg(ctypes.Structure):  # tt_hashgrid_cfg
 
 TT_R_PER_SAMPLE = 1
 TT_R_EXACT_F32 = 2
+TT_R_WGRAD_F32 = 4
 TT_Q_NORMAL = 1
 TT_Q_TEX = 2
 TT_Q_EXACT_F32 = 4

@@ -100,15 +100,124 @@ __device__ __forceinline__ float rowsum32(const float* Xs, int lane) {
     return s;
 }
 
+// ---- weight-gradient outer products on the fp16 pipe -----------------------------------------------------------------
+// acc[m][n] += X[32m.., s] Y[32n.., s]^T over the 32 samples of the tile, as 2-term split-fp16 products (tt_mfma16.h)
+// with PER-LAUNCH operand scales (powers of two from rigorous magnitude bounds, wg16_scale below): nothing is ever
+// rescaled inside the sample loop, so the persistent accumulators are touched by MFMAs only (per-tile or per-wave
+// "sticky" scales need in-loop arithmetic on the 96-160 accumulator registers, which makes the allocator spill: measured
+// in round 2).  An operand entry v is staged as ONE dword (hi | lo << 16), hi = f16(v sc), lo = f16(v sc - hi), in the
+// same [index][sample] scratch as the fp32 form.  The two halves of a dword are fed to the MFMA as two ADJACENT k-slots:
+// a k-step of 16 slots is 8 samples, slot 2d = hi, slot 2d + 1 = lo of the lane's d-th sample, for both operands -- so
+//     mfma(A, B)          = sum_s (hi_x hi_y + lo_x lo_y)
+//     mfma(A, rot16(B))   = sum_s (hi_x lo_y + lo_x hi_y)
+// together the FULL product of the two split numbers: 8 MFMAs of 32 cycles per 32 x 32 tile instead of 16 fp32 MFMAs of
+// 64, no de-interleaving, one v_alignbit per B dword.  Error per product term <= 2^-22 of the operands' global maxima:
+// fp32-grade for a sum over all samples (the fp32 accumulator itself resolves 2^-24 of the running sum).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 2^(141 - E) for a bound with biased exponent E: maps [0, bound] into the fp16 range (bound -> [2^14, 2^15))
+__device__ __forceinline__ float wg16_scale(float bound) {
+    int E = (int)(__builtin_bit_cast(unsigned, bound * 1.0001f) >> 23) & 0xff;
+    E = E < 16 ? 16 : (E > 240 ? 240 : E);
+    return __builtin_bit_cast(float, (unsigned)(268 - E) << 23);
+}
+__device__ __forceinline__ unsigned wg16_pack(float x) {  // (hi | lo << 16), both round-toward-zero: hi + lo ~ x
+    // (hi by masking the fp32 significand to 11 bits instead of the convert / convert-back pair: same speed, measured)
+    const unsigned p = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, 0.f));
+    const float hf = (float)__builtin_bit_cast(h2_t, p).x;
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, x - hf));
+}
+template <int N>
+__device__ __forceinline__ void stage_rows16(float* S, const float (&v)[N / 2], int j, int hi, float sc) {
+    unsigned* U = reinterpret_cast<unsigned*>(S);
+#pragma unroll
+    for (int r = 0; r < N / 2; ++r) U[LIDX(r, hi) * XS + j] = wg16_pack(v[r] * sc);
+}
+template <int N, int OFF, int TOT>
+__device__ __forceinline__ void stage_rows16_sub(float* S, const float (&v)[TOT], int j, int hi, float sc) {
+    unsigned* U = reinterpret_cast<unsigned*>(S);
+#pragma unroll
+    for (int r = 0; r < N / 2; ++r) U[LIDX(r, hi) * XS + j] = wg16_pack(v[OFF + r] * sc);
+}
+__device__ __forceinline__ h8_t wg16_frag(const float* S, int row, int t, int hi) {
+    return __builtin_bit_cast(h8_t, *reinterpret_cast<const u32x4*>(S + row * XS + 8 * t + 4 * hi));
+}
+__device__ __forceinline__ h8_t wg16_swap(h8_t v) {
+    u32x4 u = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) u[d] = __builtin_amdgcn_alignbit(u[d], u[d], 16);
+    return __builtin_bit_cast(h8_t, u);
+}
+template <int NX, int NY>
+__device__ __forceinline__ void wgrad16(f32x16 (&acc)[NX / 32][NY / 32], const float* Xs, const float* Ys, int i,
+                                        int hi) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // k-step: samples 8 t .. 8 t + 7 (this half-wave: 8 t + 4 hi .. + 3)
+        h8_t xa[NX / 32], yb[NY / 32], ys[NY / 32];
+#pragma unroll
+        for (int m = 0; m < NX / 32; ++m) xa[m] = wg16_frag(Xs, 32 * m + i, t, hi);
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n) {
+            yb[n] = wg16_frag(Ys, 32 * n + i, t, hi);
+            ys[n] = wg16_swap(yb[n]);
+        }
+#pragma unroll
+        for (int m = 0; m < NX / 32; ++m)
+#pragma unroll
+            for (int n = 0; n < NY / 32; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m], yb[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NX / 32; ++m)
+#pragma unroll
+            for (int n = 0; n < NY / 32; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m], ys[n], acc[m][n], 0, 0, 0);
+    }
+}
+// one 32-row slice of the left operand (see wgrad_row)
+template <int NY>
+__device__ __forceinline__ void wgrad16_row(f32x16 (&acc)[NY / 32], const float* Xs, const float* Ys, int i, int hi) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const h8_t xa = wg16_frag(Xs, i, t, hi);
+        h8_t yb[NY / 32], ys[NY / 32];
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n) {
+            yb[n] = wg16_frag(Ys, 32 * n + i, t, hi);
+            ys[n] = wg16_swap(yb[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, yb[n], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, ys[n], acc[n], 0, 0, 0);
+    }
+}
+
+// workgroup-wide max of a per-thread value through a shared word (all threads call; v >= 0)
+__device__ __forceinline__ float block_max(float v, unsigned* word) {
+    __syncthreads();
+    if (threadIdx.x == 0) *word = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(word, __builtin_bit_cast(unsigned, v));
+    __syncthreads();
+    const float r = __builtin_bit_cast(float, *word);
+    __syncthreads();
+    return r;
+}
+
+// dst += acc * ux * uy  (ux, uy: the inverse operand scales of the fp16 outer products, 1 for the fp32 ones; two
+// factors so that extreme scales cannot overflow their product)
 template <int NX, int NY>
 __device__ __forceinline__ void flush_wgrad(const f32x16 (&acc)[NX / 32][NY / 32], float* __restrict__ dst, int i,
-                                            int hi) {
+                                            int hi, float ux = 1.f, float uy = 1.f) {
 #pragma unroll
     for (int m = 0; m < NX / 32; ++m)
 #pragma unroll
         for (int n = 0; n < NY / 32; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(dst + (32 * m + LIDX(r, hi)) * NY + 32 * n + i, acc[m][n][r]);
+            for (int r = 0; r < 16; ++r)
+                atomicAdd(dst + (32 * m + LIDX(r, hi)) * NY + 32 * n + i, (acc[m][n][r] * ux) * uy);
 }
 
 #define ZERO16 \
@@ -460,7 +569,7 @@ struct BwdGeoParams {
 #define GOFF_W2T (GOFF_W1T + IMG16_FLOATS(32, 64))
 #define LDS_GEO16_FLOATS (GOFF_W2T + IMG16_FLOATS(64, 64))
 
-template <bool EXACT>
+template <bool EXACT, bool WG16>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     __shared__ __attribute__((aligned(16))) float L[LDS_GEO16_FLOATS + 4 * (GEO_SCRATCH_FLOATS + SCATTER_TAG_INTS)];
     {
@@ -472,6 +581,35 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         stage_weights_t<EXACT, 64, 64>(L + GOFF_W2T, w.w2);
     }
     const tt_render_cfg& cfg = p.cfg;
+    // ---- per-launch operand scales of the fp16 outer products dW1 += a1 u^T, dW2 += a2 v^T (wgrad16 above) ----
+    // rigorous magnitude bounds from the weights and the launch's maxima (planes, upstream: reduced on the stream in front
+    // of this kernel into the queue slot, tt_host.h):   |a2| <= max |w3|,   |a1_j| <= sum_i |W2[i][j]| |w3_i|,
+    //   |f| <= 3 P,  |h1| <= max_i ||W1_i||_1 3 P,  |u| = |sum_corners coef texel| <= 3 P (Sb + 2 (ju + jv) Gb)  (the four
+    //   bilinear weights of a plane sum to <= 1, their derivatives to <= 2 per axis),  |qbar| = |u - sbar f| <= 3 P 2 (ju +
+    //   jv) Gb,  |b1bar| <= max_i ||W1_i||_1 |qbar|,  |v| = |sbar h1 + b1bar|.
+    float sA1 = 1.f, sU = 1.f, sA2 = 1.f, sV = 1.f;
+    if (WG16) {
+        const unsigned* bnd = reinterpret_cast<const unsigned*>(p.queue) + TT_SLOT_BOUNDS;
+        const float Pm = __builtin_bit_cast(float, bnd[TT_BOUND_PLANES]), Sb = __builtin_bit_cast(float, bnd[TT_BOUND_UP0]),
+                    Gb = __builtin_bit_cast(float, bnd[TT_BOUND_UP1]);
+        unsigned* word = reinterpret_cast<unsigned*>(L + LDS_GEO16_FLOATS);  // scratch is free until the main loop
+        const int t = threadIdx.x;
+        float w1row = 0.f, a1col = 0.f, w3abs = 0.f;
+        if (t < 64) {
+            for (int c = 0; c < 32; ++c) w1row += __builtin_fabsf(p.w.w1[t * 32 + c]);
+            for (int r = 0; r < 64; ++r) a1col += __builtin_fabsf(p.w.w2[r * 64 + t]) * __builtin_fabsf(p.w.w3[r]);
+            w3abs = __builtin_fabsf(p.w.w3[t]);
+        }
+        const float W1max = block_max(w1row, word), A1max = block_max(a1col, word), A2max = block_max(w3abs, word);
+        const float jsum = (0.5f * cfg.plane_w + 0.5f * cfg.plane_h) / cfg.radius;
+        const float Fmax = 3.f * Pm, H1max = W1max * Fmax;
+        const float Umax = Fmax * (Sb + 2.f * jsum * Gb), QBmax = Fmax * 2.f * jsum * Gb;
+        const float Vmax = Sb * H1max + W1max * QBmax;
+        sA1 = wg16_scale(A1max);
+        sU = wg16_scale(Umax);
+        sA2 = wg16_scale(A2max);
+        sV = wg16_scale(Vmax);
+    }
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5, wave_in_blk = threadIdx.x >> 6;
     float* Xs = L + LDS_GEO16_FLOATS + wave_in_blk * (GEO_SCRATCH_FLOATS + SCATTER_TAG_INTS);
@@ -577,13 +715,21 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 float qb[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) qb[r] = fmaf(-sbar, f[r], u[r]);  // qbar = J gbar = u - sbar f
-                const bool region = cfg.flags >= 0;  // always true, opaque: see the texture kernel
+                // (no opaque scheduling region here, unlike the texture kernel: with the outer products on the fp16 pipe
+                // this kernel has register slack and one scheduling region is faster: 3.22 -> 3.14 ms)
+                const bool region = WG16 ? true : cfg.flags >= 0;  // (always true; opaque to the compiler unless WG16)
                 const bool do_wgrad = region && !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
                 // dW1 += a1 (sbar f + qbar)^T
                 if (do_wgrad) {
-                    stage_rows<64>(Xs, a1, i, hi);
-                    stage_rows<32>(Ys, u, i, hi);
-                    wgrad<64, 32>(accW1, Xs, Ys, i, hi);
+                    if (WG16) {
+                        stage_rows16<64>(Xs, a1, i, hi, sA1);
+                        stage_rows16<32>(Ys, u, i, hi, sU);
+                        wgrad16<64, 32>(accW1, Xs, Ys, i, hi);
+                    } else {
+                        stage_rows<64>(Xs, a1, i, hi);
+                        stage_rows<32>(Ys, u, i, hi);
+                        wgrad<64, 32>(accW1, Xs, Ys, i, hi);
+                    }
                 }
                 TT_PHASE(7);
                 // a1bar = W1 qbar ; b1bar = m1 . a1bar ; v = sbar h1 + b1bar
@@ -597,9 +743,15 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 TT_PHASE(4);
                 // dW2 += a2 v^T
                 if (do_wgrad) {
-                    stage_rows<64>(Xs, a2, i, hi);
-                    stage_rows<64>(Ys, v, i, hi);
-                    wgrad<64, 64>(accW2, Xs, Ys, i, hi);
+                    if (WG16) {
+                        stage_rows16<64>(Xs, a2, i, hi, sA2);
+                        stage_rows16<64>(Ys, v, i, hi, sV);
+                        wgrad16<64, 64>(accW2, Xs, Ys, i, hi);
+                    } else {
+                        stage_rows<64>(Xs, a2, i, hi);
+                        stage_rows<64>(Ys, v, i, hi);
+                        wgrad<64, 64>(accW2, Xs, Ys, i, hi);
+                    }
                 }
                 TT_PHASE(8);
                 // a2bar = W2 b1bar ; dw3 += sbar h2 + m2 . a2bar
@@ -643,8 +795,8 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         for (int k = 0; k < 20; ++k) atomicAdd(p.phase_cycles + 20 + k, ph_acc[k]);
 #endif
     // ---- flush the persistent weight-gradient accumulators ----
-    flush_wgrad<64, 32>(accW1, p.grads.w1, i, hi);
-    flush_wgrad<64, 64>(accW2, p.grads.w2, i, hi);
+    flush_wgrad<64, 32>(accW1, p.grads.w1, i, hi, 1.f / sA1, 1.f / sU);
+    flush_wgrad<64, 64>(accW2, p.grads.w2, i, hi, 1.f / sA2, 1.f / sV);
     atomicAdd(p.grads.w3 + lane, accw3);
 }
 
@@ -684,7 +836,7 @@ struct BwdTexParams {
 #define TEX_W16_FLOATS (TV2T + IMG16_FLOATS(64, 64))
 #define TEX_SCRATCH_FLOATS (128 * XS)
 
-template <bool EXACT>
+template <bool EXACT, bool WG16>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     __shared__ __attribute__((aligned(16))) float Lt[TEX_W16_FLOATS + 4 * (TEX_SCRATCH_FLOATS + SCATTER_TAG_INTS)];
     {
@@ -696,6 +848,34 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         stage_weights_t<EXACT, 64, 64>(Lt + TV2T, w.v2);
     }
     const tt_render_cfg& cfg = p.cfg;
+    // ---- per-launch operand scales of the fp16 outer products dV1 += k1bar e^T, dV2 += k2bar k1^T (wgrad16) ----
+    // bounds:  |e| <= P (bilinear weights are a convex combination),  |k1_i| <= ||V1_i||_1 P,
+    //   |cbar| <= |shrink| 1.002 / 4 Gr + Gf  (weights <= 1, sigmoid' <= 1/4; Gr / Gf = max |g_rgb| / |g_features|),
+    //   |k2bar_i| <= sum_o |V3[o][i]| |cbar|,   |k1bar_j| <= sum_i |V2[i][j]| (bound of k2bar_i).
+    float sKB1 = 1.f, sE = 1.f, sK2B = 1.f, sK1 = 1.f;
+    if (WG16) {
+        const unsigned* bnd = reinterpret_cast<const unsigned*>(p.queue) + TT_SLOT_BOUNDS;
+        const float Pm = __builtin_bit_cast(float, bnd[TT_BOUND_PLANES]), Gr = __builtin_bit_cast(float, bnd[TT_BOUND_UP0]),
+                    Gf = __builtin_bit_cast(float, bnd[TT_BOUND_UP1]);
+        unsigned* word = reinterpret_cast<unsigned*>(Lt + TEX_W16_FLOATS);  // scratch is free until the main loop
+        const int t = threadIdx.x;
+        const float CBmax = __builtin_fabsf(cfg.rgb_grad_shrink) * (1.002f * 0.25f) * Gr + Gf;
+        float v1row = 0.f, k2b = 0.f, kb1 = 0.f;
+        if (t < 64) {
+            for (int c = 0; c < 96; ++c) v1row += __builtin_fabsf(p.w.v1[t * 96 + c]);
+            for (int o = 0; o < 3; ++o) k2b += __builtin_fabsf(p.w.v3[o * 64 + t]);
+            for (int r = 0; r < 64; ++r) {
+                float c3 = 0.f;
+                for (int o = 0; o < 3; ++o) c3 += __builtin_fabsf(p.w.v3[o * 64 + r]);
+                kb1 += __builtin_fabsf(p.w.v2[r * 64 + t]) * c3;
+            }
+        }
+        const float V1max = block_max(v1row, word), K2Bw = block_max(k2b, word), KB1w = block_max(kb1, word);
+        sE = wg16_scale(Pm);
+        sK1 = wg16_scale(V1max * Pm);
+        sK2B = wg16_scale(K2Bw * CBmax);
+        sKB1 = wg16_scale(KB1w * CBmax);
+    }
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5, wave_in_blk = threadIdx.x >> 6;
     // per-wave scratch: rows 0..31 = Xs (transposition window / first half of bigger operands), rows 32..127 = Ys
@@ -812,7 +992,12 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         // effect; found by noticing that the -DTT_TUNING build, whose ablation branches are live, was FASTER.)
         const bool region = cfg.flags >= 0;
         const bool do_wgrad = region && !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
-        if (do_wgrad) stage_rows<96>(Ys, e, i, hi);
+        if (do_wgrad) {
+            if (WG16)
+                stage_rows16<96>(Ys, e, i, hi, sE);
+            else
+                stage_rows<96>(Ys, e, i, hi);
+        }
         TT_PHASE(2);
         float k1[32], k2[32];
         mvx<EXACT, 64, 96>(Lt + TV1, e, k1, i, hi);
@@ -870,41 +1055,58 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             // ---- dV1 += k1bar e^T  (e parked in Ys rows 0..95; k1bar through the 32-row window, half by half) ----
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                if (h2 == 0)
-                    stage_rows_sub<32, 0, 32>(Xs, kb1, i, hi);
-                else
-                    stage_rows_sub<32, 16, 32>(Xs, kb1, i, hi);
-                wgrad_row<64>(accV1a[h2], Xs, Ys, i, hi);
-                wgrad_row<32>(accV1b[h2], Xs, Ys + 64 * XS, i, hi);
+                if (WG16) {
+                    if (h2 == 0)
+                        stage_rows16_sub<32, 0, 32>(Xs, kb1, i, hi, sKB1);
+                    else
+                        stage_rows16_sub<32, 16, 32>(Xs, kb1, i, hi, sKB1);
+                    wgrad16_row<64>(accV1a[h2], Xs, Ys, i, hi);
+                    wgrad16_row<32>(accV1b[h2], Xs, Ys + 64 * XS, i, hi);
+                } else {
+                    if (h2 == 0)
+                        stage_rows_sub<32, 0, 32>(Xs, kb1, i, hi);
+                    else
+                        stage_rows_sub<32, 16, 32>(Xs, kb1, i, hi);
+                    wgrad_row<64>(accV1a[h2], Xs, Ys, i, hi);
+                    wgrad_row<32>(accV1b[h2], Xs, Ys + 64 * XS, i, hi);
+                }
             }
             TT_PHASE(7);
             // ---- dV2 += k2bar k1^T  (e is dead: k2bar in rows 0..63, k1 in rows 64..127) ----
-            stage_rows<64>(Xs, k2, i, hi);
-            stage_rows<64>(Xs + 64 * XS, k1, i, hi);
-            wgrad<64, 64>(accV2, Xs, Xs + 64 * XS, i, hi);
+            if (WG16) {
+                stage_rows16<64>(Xs, k2, i, hi, sK2B);
+                stage_rows16<64>(Xs + 64 * XS, k1, i, hi, sK1);
+                wgrad16<64, 64>(accV2, Xs, Xs + 64 * XS, i, hi);
+            } else {
+                stage_rows<64>(Xs, k2, i, hi);
+                stage_rows<64>(Xs + 64 * XS, k1, i, hi);
+                wgrad<64, 64>(accV2, Xs, Xs + 64 * XS, i, hi);
+            }
             TT_PHASE(8);
         }
         // ---- ebar = V1^T k1bar (one plane at a time) ; scatter texel(3+p, c)[ch] += w_c * ebar[32p + ch] ----
         if (region && !TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
+            // the combine GEMM on the fp16 pipe as in the geometry kernel (round 2 measured +26 spilled registers and
+            // 3.88 -> 4.16 ms for this; with the outer products on the fp16 pipe it fits: 3.65 -> 3.37 ms)
+            constexpr bool SC_EXACT = EXACT || !WG16;  // (the TT_R_WGRAD_F32 A/B variant = the round-2 kernel)
             float* M = Xs;              // rows 0..63: the slot x sample coefficient matrix (fp32), row 64: dump row
-            float* Es = Xs + 65 * XS;   // ebar rows staged as [sample][32], stride 33, then the fallback lists
-            scatter_clear<true>(M, lane);
+            float* Es = Xs + (SC_EXACT ? 65 * XS : SCATTER_M_FLOATS);  // ebar rows [sample][32], stride 33; fallback lists
+            scatter_clear<SC_EXACT>(M, lane);
             // ebar = V1^T k1bar for the three planes in ONE product (96 rows: k1bar is split into fp16 terms once)
             float eb[48];
             mvtx<EXACT, 96, 64, V1S>(Lt + TV1T, Lt + TV1, kb1, eb, i, hi);
             TT_PHASE(9);
             const int tex0 = (int)(pofs / TT_C);
-            // (fp32 combine GEMM here: the split-fp16 one costs this kernel 26 more spilled registers, 3.88 -> 4.16 ms)
-            scatter_planes<true>(grad_out, grad_bytes, Es, M, tags, Es + 32 * 33, i, hi, [&](int pl, PlaneRefs& refs) {
+            scatter_planes<SC_EXACT>(grad_out, grad_bytes, Es, M, tags, Es + 32 * 33, i, hi, [&](int pl, PlaneRefs& refs) {
                 Corners c;
                 corners_setup(PLANE_U(pl, X, Y, Z), PLANE_V(pl, X, Y, Z), H, W, valid, c);
                 int aoff[4];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4)  // absolute texel index, prompt included
                     aoff[q4] = tex0 + (int)((3 + pl) * HW) + c.off[q4];
-                refs = plane_refs<false>(c.w, aoff, c.hs, hi);
+                refs = plane_refs<!SC_EXACT>(c.w, aoff, c.hs, hi);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[16 * pl + r];
+                for (int r = 0; r < 16; ++r) Es[i * 33 + LIDX(r, hi)] = eb[16 * pl + r] * refs.qs;
             }
 #ifdef TT_TUNING
             , scat_st
@@ -927,11 +1129,12 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * m + LIDX(r, hi);
-            atomicAdd(p.grads.v1 + row * 96 + i, accV1a[m][0][r]);
-            atomicAdd(p.grads.v1 + row * 96 + 32 + i, accV1a[m][1][r]);
-            atomicAdd(p.grads.v1 + row * 96 + 64 + i, accV1b[m][0][r]);
+            const float u1 = 1.f / sKB1, u2 = 1.f / sE;  // inverse operand scales (1 for the fp32 outer products)
+            atomicAdd(p.grads.v1 + row * 96 + i, (accV1a[m][0][r] * u1) * u2);
+            atomicAdd(p.grads.v1 + row * 96 + 32 + i, (accV1a[m][1][r] * u1) * u2);
+            atomicAdd(p.grads.v1 + row * 96 + 64 + i, (accV1b[m][0][r] * u1) * u2);
         }
-    flush_wgrad<64, 64>(accV2, p.grads.v2, i, hi);
+    flush_wgrad<64, 64>(accV2, p.grads.v2, i, hi, 1.f / sK2B, 1.f / sK1);
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -998,6 +1201,68 @@ extern "C" int tt_tuning_phase_cycles(unsigned long long* out40) {
     return hipMemset(g_phase_cycles, 0, 40 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
 }
 #endif
+// ---- per-launch magnitude bounds for the fp16 outer products (tt_host.h: TT_SLOT_BOUNDS) --------------------------
+// max |x| over flat float4 data, raised into *out with one atomicMax per workgroup (non-negative floats order like their
+// bit patterns; NaN / Inf patterns order above every finite value and end up clamped by wg16_scale).
+__global__ __launch_bounds__(256) void k_absmax4(const f32x4* __restrict__ x, long long n4, long long seg4,
+                                                 long long seg_stride4, unsigned* __restrict__ out0,
+                                                 unsigned* __restrict__ out1) {
+    // n4 float4 elements in segments of seg4 elements that start seg_stride4 apart (seg4 == seg_stride4: contiguous).
+    // out0 <- max |.x| (and, if out1 is null, of the other three components as well); out1 <- max |.y|, |.z|, |.w|
+    float m0 = 0.f, m1 = 0.f;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+        const long long sgm = e / seg4;
+        const f32x4 v = x[sgm * seg_stride4 + (e - sgm * seg4)];
+        m0 = fmaxf(m0, __builtin_fabsf(v[0]));
+        m1 = fmaxf(m1, fmaxf(__builtin_fabsf(v[1]), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+    }
+    if (!out1) m0 = fmaxf(m0, m1);
+    __shared__ unsigned w[2];
+    if (threadIdx.x < 2) w[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, o));
+        m1 = fmaxf(m1, __shfl_xor(m1, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&w[0], __builtin_bit_cast(unsigned, m0));
+        atomicMax(&w[1], __builtin_bit_cast(unsigned, m1));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(out0, w[0]);
+        if (out1) atomicMax(out1, w[1]);
+    }
+}
+// flat float data of any length (g_rgb: n_rays x 3, g_features: n x 3): scalar loads
+__global__ __launch_bounds__(256) void k_absmax1(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, __builtin_fabsf(x[e]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ unsigned w;
+    if (threadIdx.x == 0) w = 0u;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) atomicMax(&w, __builtin_bit_cast(unsigned, m));
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, w);
+}
+static unsigned absmax_blocks(long long n) {
+    long long b = (n + 256 * 8 - 1) / (256 * 8);
+    return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+// max |texel| of planes first_plane .. first_plane + 2 of every prompt of the packed buffer
+static void launch_planes_bound(const float* packed, const tt_render_cfg& cfg, int first_plane, unsigned* out,
+                                hipStream_t s) {
+    const long long hw4 = (long long)cfg.plane_h * cfg.plane_w * TT_C / 4;  // float4s per plane
+    const long long n4 = 3 * hw4 * cfg.n_prompts;
+    hipLaunchKernelGGL(k_absmax4, dim3(absmax_blocks(n4)), dim3(256), 0, s,
+                       reinterpret_cast<const f32x4*>(packed) + first_plane * hw4, n4, 3 * hw4, 6 * hw4, out,
+                       (unsigned*)nullptr);
+}
+
+static bool use_wg16(const tt_render_cfg& cfg) { return !(cfg.flags & (TT_R_EXACT_F32 | TT_R_WGRAD_F32)); }
+
 static void launch_bwd_geo(const BwdGeoParams& p0, long long blocks, hipStream_t s) {
     BwdGeoParams p = p0;
 #ifdef TT_TUNING
@@ -1005,10 +1270,18 @@ static void launch_bwd_geo(const BwdGeoParams& p0, long long blocks, hipStream_t
 #else
     p.phase_cycles = nullptr;
 #endif
-    if (p.cfg.flags & TT_R_EXACT_F32)
-        hipLaunchKernelGGL(k_decode_bwd_geo<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(k_decode_bwd_geo<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (use_wg16(p.cfg)) {
+        unsigned* bnd = reinterpret_cast<unsigned*>(p.queue) + TT_SLOT_BOUNDS;
+        launch_planes_bound(p.packed, p.cfg, 0, bnd + TT_BOUND_PLANES, s);
+        const long long n = p.cfg.n_rays * p.cfg.n_samples;  // upstream float4 (d sdf, d sdf_grad) per sample
+        hipLaunchKernelGGL(k_absmax4, dim3(absmax_blocks(n)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(p.ws), n, n,
+                           n, bnd + TT_BOUND_UP0, bnd + TT_BOUND_UP1);
+        hipLaunchKernelGGL((k_decode_bwd_geo<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else if (p.cfg.flags & TT_R_EXACT_F32) {
+        hipLaunchKernelGGL((k_decode_bwd_geo<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((k_decode_bwd_geo<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    }
 }
 static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t s) {
     BwdTexParams p = p0;
@@ -1017,10 +1290,22 @@ static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t
 #else
     p.phase_cycles = nullptr;
 #endif
-    if (p.cfg.flags & TT_R_EXACT_F32)
-        hipLaunchKernelGGL(k_decode_bwd_tex<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(k_decode_bwd_tex<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (use_wg16(p.cfg)) {
+        unsigned* bnd = reinterpret_cast<unsigned*>(p.queue) + TT_SLOT_BOUNDS;
+        launch_planes_bound(p.packed, p.cfg, 3, bnd + TT_BOUND_PLANES, s);  // (p.packed may be slid by 3 planes: points)
+        if (p.g_rgb)
+            hipLaunchKernelGGL(k_absmax1, dim3(absmax_blocks(p.cfg.n_rays * 3)), dim3(256), 0, s, p.g_rgb,
+                               (long long)p.cfg.n_rays * 3, bnd + TT_BOUND_UP0);
+        if (p.g_features) {
+            const long long n = p.cfg.n_rays * p.cfg.n_samples * 3;
+            hipLaunchKernelGGL(k_absmax1, dim3(absmax_blocks(n)), dim3(256), 0, s, p.g_features, n, bnd + TT_BOUND_UP1);
+        }
+        hipLaunchKernelGGL((k_decode_bwd_tex<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else if (p.cfg.flags & TT_R_EXACT_F32) {
+        hipLaunchKernelGGL((k_decode_bwd_tex<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((k_decode_bwd_tex<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    }
 }
 
 int tt_launch_march_bwd(const float* rays_d, const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,

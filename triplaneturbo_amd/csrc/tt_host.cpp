@@ -28,7 +28,8 @@ int tt_num_cus() {
 }
 
 namespace {
-// Work-queue counter slots: 64 B each (8 per-XCD heads + padding: one cache line).
+// Work-queue counter slots: TT_SLOT_INTS ints each (8 per-XCD heads + a steal counter, then the per-launch magnitude
+// bounds of the backward kernels' fp16 outer products, tt_host.h).
 //   * eager launches: a RING of kRing slots per (device, stream).  Launches on a stream are ordered and every launch
 //     first enqueues a one-wave kernel that zeroes ITS slot on that stream, so a slot is clean whatever happened to the
 //     previous kernel that used it (fault, kill), two launches that may run concurrently (different streams) never
@@ -41,7 +42,7 @@ namespace {
 //     kGraphSlots captured launches alive in graphs that replay CONCURRENTLY, and more than kStreams streams with
 //     launches in flight at once (the oldest stream entry is recycled, without a device-wide synchronisation -- which
 //     would be illegal while another stream is capturing).
-constexpr int kMaxDevices = 64, kStreams = 256, kRing = 4, kGraphSlots = 4096, kSlotInts = 16;
+constexpr int kMaxDevices = 64, kStreams = 256, kRing = 4, kGraphSlots = 4096, kSlotInts = TT_SLOT_INTS;
 struct DeviceScratch {
     int* base = nullptr;             // (kStreams * kRing + kGraphSlots) * kSlotInts ints
     hipStream_t streams[kStreams];   // stream owning eager ring i

@@ -22,3 +22,11 @@ long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom*
 // (see tt_host.cpp).  Returns nullptr on a HIP error.  (The only state the library keeps: a 328 KB allocation per
 // device, never freed; its first use must not happen inside a stream capture.)
 int* tt_queue_counters(hipStream_t stream);
+// layout of a slot (ints): [0..8] queue heads; [TT_SLOT_BOUNDS + k] = bit pattern of a non-negative float, raised with
+// atomicMax by the reduction kernels launched in front of a backward kernel (tt_backward.hip: magnitude bounds of the
+// operands of the split-fp16 weight-gradient outer products); everything is zeroed together with the queue heads.
+#define TT_SLOT_INTS 32
+#define TT_SLOT_BOUNDS 16
+#define TT_BOUND_PLANES 0   /* max |texel| of the three planes the kernel reads */
+#define TT_BOUND_UP0 1      /* geometry: max |d/d sdf|;            texture: max |g_rgb| */
+#define TT_BOUND_UP1 2      /* geometry: max |d/d sdf_grad| comp.; texture: max |g_features| */

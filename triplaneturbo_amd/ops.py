@@ -108,6 +108,7 @@ class RenderConfig:
     grad_copies: int = 1  # privatised copies of the plane-gradient buffer in the backward (performance knob)
     tile_chunk: int = 0  # samples of a ray block per work item (performance knob); 0 = automatic
     exact_f32: bool = False  # TT_R_EXACT_F32: all matrix products on the fp32-input MFMA (A/B reference, ~1.6x slower)
+    wgrad_f32: bool = False  # TT_R_WGRAD_F32: weight-gradient outer products on the fp32 MFMA (A/B of the fp16 ones)
 
 
 def planes_pack(space_cache: Tensor) -> Tensor:
@@ -332,7 +333,8 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
     inv_std = min(max(float(rc.inv_std), 1.0e-6), 1.0e6)  # LearnedVariance.forward clamp, renderer :34-35
     return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
                           inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
-                          (_lib.TT_R_PER_SAMPLE if per_sample else 0) | (_lib.TT_R_EXACT_F32 if rc.exact_f32 else 0),
+                          (_lib.TT_R_PER_SAMPLE if per_sample else 0) | (_lib.TT_R_EXACT_F32 if rc.exact_f32 else 0) |
+                          (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0),
                           image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0, int(rc.tile_sb),
                           max(1, int(rc.grad_copies)), max(0, int(rc.tile_chunk)))
 
