@@ -382,6 +382,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-f32 sub-result and the secondary workloads")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # body of a rocprofv3 pass: steps only
     ap.add_argument("--lib-variant", default=None, help=argparse.SUPPRESS)  # dev A/B: an experiment build of the library
+    ap.add_argument("--tile-sb", type=int, default=0, help=argparse.SUPPRESS)      # dev sweeps of the performance knobs
+    ap.add_argument("--tile-chunk", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
@@ -423,7 +425,8 @@ def main():
     R, Hh, Ww, S = 256, 256, 256, 128
     inp = make_inputs(rank, world, device, args.config, R, Hh, Ww, S)
     P = inp["cache"].shape[0]
-    rc = ops.RenderConfig(exact_f32=args.exact_f32, wgrad_f32=args.wgrad_f32)
+    rc = ops.RenderConfig(exact_f32=args.exact_f32, wgrad_f32=args.wgrad_f32, tile_sb=args.tile_sb,
+                          tile_chunk=args.tile_chunk)
     bucket = FlatGradBucket(inp["sw"] + inp["fw"])  # MLP grads = views of one buffer: one collective, no cat / copies
     fused = not args.torch_loss
 
