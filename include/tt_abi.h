@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 11
+#define TT_ABI_VERSION 12
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -122,6 +122,14 @@ typedef struct {
                                   same-texel atomics.  0/1 = a single copy */
     int32_t tile_chunk;        /* samples of a ray block per work item of the dynamic queue; 0 = automatic (performance
                                   only, like tile_sb) */
+    float skip_eps_tex;        /* backward, OPT-IN approximation (0 = exact, the default): a 32-sample tile whose upstream
+                                  colour gradients all satisfy |cbar|_1 <= skip_eps_tex is skipped by tt_render_bwd_tex
+                                  (cbar = d loss / d raw feature = shrink w g_rgb 1.002 s (1 - s) + g_features: samples in
+                                  empty space carry weights ~1e-5 and almost no gradient).  Induced error of d/d texture
+                                  planes and d/d feature net: at most skip_eps_tex x (skipped samples) x the local
+                                  sensitivity; measured at the training shapes in tests/test_gpu_skip.py. */
+    float skip_eps_geo;        /* the same for tt_render_bwd_geo on |d loss/d sdf| + |d loss/d sdf_grad|_1 per sample (dense
+                                  under an eikonal loss, so usually nothing to skip there) */
 } tt_render_cfg;
 
 #define TT_R_PER_SAMPLE 1 /* also write per-sample sdf / sdf_grad / features (training extras, renderer :532-545) */

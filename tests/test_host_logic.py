@@ -164,7 +164,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == 11
+    assert lib.tt_abi_version() == 12
     assert b"bad argument" in lib.tt_strerror(-1)
 
 
@@ -174,9 +174,10 @@ def test_ctypes_struct_layout_matches_header(tmp_path):
 #include <stddef.h>
 #include "tt_abi.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tt_render_cfg), offsetof(tt_render_cfg, n_rays),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tt_render_cfg), offsetof(tt_render_cfg, n_rays),
          offsetof(tt_render_cfg, radius), offsetof(tt_render_cfg, flags), offsetof(tt_render_cfg, image_w),
-         offsetof(tt_render_cfg, tile_chunk), sizeof(tt_mlp_weights), sizeof(tt_mlp_grads));
+         offsetof(tt_render_cfg, tile_chunk), sizeof(tt_mlp_weights), sizeof(tt_mlp_grads),
+         offsetof(tt_render_cfg, skip_eps_geo));
   return 0; }'''
     src = tmp_path / "t.c"
     src.write_text(code)
@@ -185,7 +186,7 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     c = _lib.RenderCfg
     got = [ctypes.sizeof(c), c.n_rays.offset, c.radius.offset, c.flags.offset, c.image_w.offset, c.tile_chunk.offset,
-           ctypes.sizeof(_lib.MlpWeights), ctypes.sizeof(_lib.MlpWeights)]
+           ctypes.sizeof(_lib.MlpWeights), ctypes.sizeof(_lib.MlpWeights), c.skip_eps_geo.offset]
     assert [int(x) for x in out] == got
 
 

@@ -117,6 +117,7 @@ class RenderCfg(ctypes.Structure):
         ("rays_per_view", _I32), ("n_samples", _I32), ("n_rays", _I64), ("radius", _F),
         ("sdf_bias_radius", _F), ("inv_std", _F), ("cos_anneal_ratio", _F), ("rgb_grad_shrink", _F),
         ("flags", _I32), ("image_w", _I32), ("tile_sb", _I32), ("grad_copies", _I32), ("tile_chunk", _I32),
+        ("skip_eps_tex", _F), ("skip_eps_geo", _F),
     ]
 
 

@@ -680,7 +680,11 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             const float vf = ray_okf * (si < s_end ? 1.f : 0.f);
             const float sbar = in.up[0] * vf, gbx = in.up[1] * vf, gby = in.up[2] * vf, gbz = in.up[3] * vf;
             TT_PHASE(0);
-            if (!__any(tt_any_nonzero4(sbar, gbx, gby, gbz))) continue;  // exact
+            // exact with skip_eps_geo = 0 (the default); > 0: the opt-in approximation of tt_abi.h.  (!(x <= eps): a NaN
+            // upstream is never skipped)
+            if (!__any(!((__builtin_fabsf(sbar) + __builtin_fabsf(gbx)) + (__builtin_fabsf(gby) + __builtin_fabsf(gbz)) <=
+                         cfg.skip_eps_geo)))
+                continue;
             float tm, px, py, pz;
             sample_position(ox, oy, oz, dx, dy, dz, in.ts, in.te, tm, px, py, pz);
             const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius),
@@ -972,7 +976,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             cb[o] = c * vf;  // 0/1 factor, not a select on a freshly combined lane mask (see k_decode_bwd_geo)
         }
         TT_PHASE(0);
-        if (!__any(tt_any_nonzero3(cb[0], cb[1], cb[2]))) continue;  // exact: nothing flows back
+        // exact with skip_eps_tex = 0 (the default: nothing flows back); > 0: the opt-in approximation of tt_abi.h
+        if (!__any(!((__builtin_fabsf(cb[0]) + __builtin_fabsf(cb[1])) + __builtin_fabsf(cb[2]) <= cfg.skip_eps_tex)))
+            continue;
 #ifdef TT_TUNING
         {  // live-lane statistics (tools/phase_cycles.py): slots 12 / 13 are unused by the timers
             const unsigned long long live = __ballot(cb[0] != 0.f || cb[1] != 0.f || cb[2] != 0.f) & 0xffffffffull;
@@ -1439,6 +1445,8 @@ static int points_cfg(tt_render_cfg* c, int32_t n_batch, int64_t n_points, int32
     c->tile_sb = 1;
     c->tile_chunk = 0;
     c->grad_copies = grad_copies;
+    c->skip_eps_tex = 0.f;
+    c->skip_eps_geo = 0.f;
     return tt_validate_cfg(c);
 }
 

@@ -665,6 +665,7 @@ int tt_validate_cfg(const tt_render_cfg* cfg) {
     if (tt_planes_too_large(cfg->n_prompts, cfg->plane_h, cfg->plane_w)) return TT_ERR_UNSUPPORTED;
     if (!(cfg->radius > 0.f) || !(cfg->inv_std > 0.f)) return TT_ERR_BAD_ARG;
     if (cfg->flags < 0) return TT_ERR_BAD_ARG;  // (the kernels use `flags >= 0` as an always-true opaque condition)
+    if (!(cfg->skip_eps_tex >= 0.f) || !(cfg->skip_eps_geo >= 0.f)) return TT_ERR_BAD_ARG;
     return TT_OK;
 }
 

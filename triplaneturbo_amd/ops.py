@@ -109,6 +109,10 @@ class RenderConfig:
     tile_chunk: int = 0  # samples of a ray block per work item (performance knob); 0 = automatic
     exact_f32: bool = False  # TT_R_EXACT_F32: all matrix products on the fp32-input MFMA (A/B reference, ~1.6x slower)
     wgrad_f32: bool = False  # TT_R_WGRAD_F32: weight-gradient outer products on the fp32 MFMA (A/B of the fp16 ones)
+    # OPT-IN approximation of the backward (0 = exact): skip 32-sample tiles whose upstream gradients are all below the
+    # threshold (tt_render_cfg.skip_eps_tex / skip_eps_geo in include/tt_abi.h; error measured in tests/test_gpu_skip.py)
+    skip_eps_tex: float = 0.0
+    skip_eps_geo: float = 0.0
 
 
 def planes_pack(space_cache: Tensor) -> Tensor:
@@ -336,7 +340,8 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
                           (_lib.TT_R_PER_SAMPLE if per_sample else 0) | (_lib.TT_R_EXACT_F32 if rc.exact_f32 else 0) |
                           (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0),
                           image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0, int(rc.tile_sb),
-                          max(1, int(rc.grad_copies)), max(0, int(rc.tile_chunk)))
+                          max(1, int(rc.grad_copies)), max(0, int(rc.tile_chunk)), max(0.0, float(rc.skip_eps_tex)),
+                          max(0.0, float(rc.skip_eps_geo)))
 
 
 def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,

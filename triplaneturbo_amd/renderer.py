@@ -126,6 +126,11 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         # where the sampler places its edges in cdf space: "tt" | "center" (sampler.py; nerfacc's own convention is
         # unverifiable in this build, so the choice is explicit).  Not a reference knob, so not in Config.
         self.sampler_placement = "tt"
+        # OPT-IN approximation of the training backward (0 = exact, like the reference): 32-sample tiles whose upstream
+        # gradients are all below the threshold are skipped (ops.RenderConfig.skip_eps_tex / skip_eps_geo;
+        # INTEGRATION.md section 5 for the measured error / speed).  Not reference knobs, so not in Config.
+        self.grad_skip_eps_tex = 0.0
+        self.grad_skip_eps_geo = 0.0
         # OPT-IN approximation for eval renders without autograd (tt_render_eval): eps > 0 stops marching a ray once its
         # transmittance is below eps and skips texture decodes of weights below eps / S; per-ray error of opacity and
         # comp_rgb < 2 eps, of depth < eps * far, of z_variance / comp_normal likewise O(eps) (measured at eps = 1e-4 on
@@ -162,7 +167,8 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         g = self.geometry.cfg
         return ops.RenderConfig(radius=self.cfg.radius, sdf_bias_radius=float(g.sdf_bias_params),
                                 inv_std=self._inv_std_value(), cos_anneal_ratio=float(self.cos_anneal_ratio),
-                                rgb_grad_shrink=float(self.rgb_grad_shrink))
+                                rgb_grad_shrink=float(self.rgb_grad_shrink), skip_eps_tex=float(self.grad_skip_eps_tex),
+                                skip_eps_geo=float(self.grad_skip_eps_geo))
 
     def sample(self, space_cache: Tensor, rays_o: Tensor, rays_d: Tensor, generator=None, packed=None):
         """ImportanceEstimator.sampling + prop_sigma_fn (estimators.py:22-101, renderer :243-316), no grad."""
