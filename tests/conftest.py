@@ -24,5 +24,8 @@ def _built_library():
     """Explicit build step (NOT a fallback): the HIP library is compiled in-tree with hipcc before any test uses it;
     a no-op when triplaneturbo_amd/libtt_hip.so is newer than its sources."""
     from triplaneturbo_amd import _lib
-    _lib.build()
+    if os.environ.get("TT_LIB_VARIANT"):  # dev only: run the suite against an experiment build (tools/build_variants.py)
+        _lib.use_variant(os.environ["TT_LIB_VARIANT"])
+    else:
+        _lib.build()
     yield

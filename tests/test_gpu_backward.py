@@ -244,3 +244,34 @@ def test_backward_is_linear_in_rays(mods):
     gf, ga, gb = grads(full), grads(a), grads(~a)
     for n, x, y, z in zip(NAMES, gf, ga, gb):
         assert _rel(y + z, x) < 2e-5, n
+
+
+@pytest.mark.parametrize("log2_scale", [-70, 45])
+def test_upstream_gradients_of_any_scale(mods, log2_scale):
+    """The fp16 outer products of the weight gradients take their operand scales from per-launch bounds of the upstream
+    gradients (tt_backward.hip, wg16_scale): a loss scaled by 2^-70 or 2^45 (AMP-style loss scaling, tiny regulariser
+    weights) must give exactly correspondingly scaled gradients -- nothing may underflow to zero or overflow fp16."""
+    ops, functional = mods
+    P, R, n_view, Hh, Ww, S, seed = 1, 32, 1, 8, 8, 24, 51
+    g = torch.Generator().manual_seed(seed)
+    cache = torch.randn(P, 6, 32, R, R, generator=g) * 0.5
+    sw = O.init_mlp_weights([32, 64, 64, 1], g)
+    fw = O.init_mlp_weights([96, 64, 64, 3], g)
+    ro, rd, c2w, cd = O.make_cameras(P * n_view, Hh, Ww)
+    ts, te = O.uniform_intervals(P * n_view * Hh * Ww, S, 0.3, 3.2)
+    bg = torch.ones(3)
+    proj = {n: torch.randn(P * n_view, Hh, Ww, c, generator=g) for n, c in KEYS}
+    rck = dict(inv_std=80.0, rgb_grad_shrink=1.0, cos_anneal_ratio=1.0)
+    _, _, g1 = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    k = 2.0 ** log2_scale
+    dev = "cuda"
+    c = cache.to(dev).requires_grad_(True)
+    sws = [w.to(dev).requires_grad_(True) for w in sw]
+    fws = [w.to(dev).requires_grad_(True) for w in fw]
+    out = functional.volume_render(c, sws, fws, ro.to(dev), rd.to(dev), ts.to(dev), te.to(dev), bg.to(dev), cd.to(dev),
+                                   c2w.to(dev), ops.RenderConfig(**rck), training=True)
+    loss = O.synthetic_loss(out, {n: v.to(dev) for n, v in proj.items()}) * k
+    g2 = [t.cpu().double() / k for t in torch.autograd.grad(loss, [c] + sws + fws)]
+    for n, a, b in zip(NAMES, g2, g1):
+        assert torch.isfinite(a).all(), n
+        assert _rel(a, b.double()) < 2e-5, (n, _rel(a, b.double()))

@@ -9,7 +9,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import triplaneturbo_amd as tt  # noqa: E402
-from triplaneturbo_amd import ops, synthetic  # noqa: E402
+from triplaneturbo_amd import _lib, ops, synthetic  # noqa: E402
+
+if os.environ.get("TT_LIB_VARIANT"):  # dev A/B of an experiment build (tools/build_variants.py)
+    _lib.use_variant(os.environ["TT_LIB_VARIANT"])
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 2
