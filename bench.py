@@ -449,7 +449,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(0 if args.graph else args.warmup):  # (--graph warms up its own step on the capture stream)
         loss = step()
     if args.pmc_child:  # body of one rocprofv3 --pmc pass: the same steps, nothing else
         for _ in range(args.steps):
@@ -461,17 +461,27 @@ def main():
     if args.graph:  # the whole step (incl. the all-reduce when N > 1 is NOT captured: N = 1 only) as one hipGraph
         if world > 1:
             raise SystemExit("--graph is an N = 1 A/B")
-        static_g = torch.zeros_like(inp["cache"])
+        params = [inp["cache"]] + inp["sw"] + inp["fw"]
+        static_g = [torch.zeros_like(t) for t in params]
+
+        def gstep():  # the same work with autograd.grad into static tensors (what tests/test_gpu_graph.py captures)
+            out = functional.volume_render(inp["cache"], inp["sw"], inp["fw"], inp["ro"], inp["rd"], inp["ts"],
+                                           inp["te"], inp["bg"], inp["cd"], inp["c2w"], rc, training=True)
+            ls = loss_fn(out, inp["proj"], fused_eikonal=fused)
+            for dst, gr in zip(static_g, torch.autograd.grad(ls, params)):
+                dst.copy_(gr)
+            return ls
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            step()
+            for _ in range(max(2, args.warmup)):
+                gstep()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            loss = step()
-            static_g.copy_(inp["cache"].grad)
+            loss = gstep()
         run = graph.replay
     else:
         run = step
@@ -527,7 +537,7 @@ def main():
         if graph is not None:  # per-kernel HIP events cannot be recorded inside a replay: time eager steps for them
             ops.set_kernel_timer(timer)
             for _ in range(5):
-                step()
+                gstep()
             ops.set_kernel_timer(None)
         ksum = timer.summary(median=True)  # label -> (median ms, launches)
         kernels = {k: dict(kernel_roofline(k, ms, n_samples, args.exact_f32), launches=n) for k, (ms, n) in ksum.items()

@@ -5,7 +5,7 @@ out=${1:-gpurun_out/prof}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats -- $CMD > $R/$out/stats.log 2>&1
 echo "stats rc=$?"
 i=0

@@ -25,7 +25,7 @@ shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 L = [f"# Round {tag[1:]} profile summary (1x MI355X, bench.py workload: 256x256 rays x 128 samples, fwd+bwd)", "",
      "command: rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 "
-     "--no-cpu-baseline   (recipe: tools/profile_round.sh, folded by tools/profile_summary.py)", "",
+     "--no-cpu-baseline --no-pmc --no-extras   (recipe: tools/profile_round.sh, folded by tools/profile_summary.py)", "",
      "## rocprofv3 --stats (top kernels)", "", "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
 for r in rows[:14]:
     L.append(f"| {r['Name'][:70]} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "

@@ -541,6 +541,8 @@ class _TriplaneRenderFn(torch.autograd.Function):
     def forward(ctx, packed, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, rays_per_view, rc,
                 image_w):
         need_grad = any(ctx.needs_input_grad[:7])
+        ctx.set_materialize_grads(False)  # unused outputs (e.g. `features`, `weights`) reach backward as None, not as
+        #                                    100 MB of zeros the kernels would have to read
         raw = render_forward_raw(packed, (w1, w2, w3), (v1, v2, v3), rays_o, rays_d, t_starts, t_ends, rays_per_view,
                                  rc, per_sample=True, image_w=image_w)
         ctx.rays_per_view = rays_per_view
