@@ -8,4 +8,7 @@ from triplaneturbo_amd import _lib  # noqa: E402
 
 for spec in sys.argv[1:]:
     name, _, defs = spec.partition("=")
-    print(_lib.build(force=True, variant=name, defines=[d for d in defs.split(",") if d]))
+    flags = [d for d in defs.split(",") if d]
+    # "@plain" drops the per-translation-unit flags of _lib.SOURCE_FLAGS (A/B of those flags themselves)
+    print(_lib.build(force=True, variant=name, defines=[f for f in flags if f != "@plain"],
+                     source_flags={} if "@plain" in flags else None))

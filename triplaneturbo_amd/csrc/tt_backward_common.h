@@ -1,0 +1,682 @@
+// tt_backward_common.h -- what the two translation units of the fused render backward share: the LDS transposition /
+// outer-product / matrix-core scatter building blocks, the per-launch bound reductions and small host helpers.
+// tt_backward.hip holds the geometry half, tt_backward_tex.hip the texture half (separate units: each kernel is
+// ~9000 instructions per loop body, and the texture unit is compiled with its own scheduler strategy, _lib.py).
+#pragma once
+#include "tt_device.h"
+#include "tt_mfma16.h"
+#include "tt_alpha.h"
+#include "tt_host.h"
+#include <stdlib.h>
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// tuning build only: cycles per phase of the texture backward, summed over waves into p.phase_cycles[16]
+#ifdef TT_TUNING
+#define TT_PHASE(k)                                              \
+    do {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+        ph_acc[k] += t_now - ph_t;                               \
+        ph_t = t_now;                                            \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#else
+#define TT_PHASE(k) \
+    do {            \
+    } while (0)
+#endif
+#define XS 36  // row stride (floats) of the [index][sample] transposition scratch
+
+// ---- LDS transposition helpers (wave-private scratch; DS ops of one wave execute in order) ----------
+template <int N>
+__device__ __forceinline__ void stage_rows(float* S, const float (&v)[N / 2], int j, int hi) {
+#pragma unroll
+    for (int r = 0; r < N / 2; ++r) S[LIDX(r, hi) * XS + j] = v[r];
+}
+// stage the N-element slice of a longer register vector that starts at register OFF
+template <int N, int OFF, int TOT>
+__device__ __forceinline__ void stage_rows_sub(float* S, const float (&v)[TOT], int j, int hi) {
+#pragma unroll
+    for (int r = 0; r < N / 2; ++r) S[LIDX(r, hi) * XS + j] = v[OFF + r];
+}
+
+// acc[m][n] += X[32m.., s] * Y[32n.., s]^T summed over the 32 samples s of the tile
+template <int NX, int NY>
+__device__ __forceinline__ void wgrad(f32x16 (&acc)[NX / 32][NY / 32], const float* Xs, const float* Ys, int i,
+                                      int hi) {
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+        f32x4 xa[NX / 32], yb[NY / 32];
+#pragma unroll
+        for (int m = 0; m < NX / 32; ++m)
+            xa[m] = *reinterpret_cast<const f32x4*>(Xs + (32 * m + i) * XS + 16 * hi + 4 * t4);
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n)
+            yb[n] = *reinterpret_cast<const f32x4*>(Ys + (32 * n + i) * XS + 16 * hi + 4 * t4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int m = 0; m < NX / 32; ++m)
+#pragma unroll
+                for (int n = 0; n < NY / 32; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[m][k], yb[n][k], acc[m][n], 0, 0, 0);
+    }
+}
+
+// one 32-row slice of the left operand: acc[n] += X[0..31, s] * Y[32n.., s]^T
+template <int NY>
+__device__ __forceinline__ void wgrad_row(f32x16 (&acc)[NY / 32], const float* Xs, const float* Ys, int i, int hi) {
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+        f32x4 yb[NY / 32];
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(Xs + i * XS + 16 * hi + 4 * t4);
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n)
+            yb[n] = *reinterpret_cast<const f32x4*>(Ys + (32 * n + i) * XS + 16 * hi + 4 * t4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int n = 0; n < NY / 32; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[k], yb[n][k], acc[n], 0, 0, 0);
+    }
+}
+
+// row sum over the 32 samples of scratch row `lane` (lane <-> index 0..63)
+__device__ __forceinline__ float rowsum32(const float* Xs, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(Xs + lane * XS + 4 * g);
+        s += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    return s;
+}
+
+// ---- weight-gradient outer products on the fp16 pipe -----------------------------------------------------------------
+// acc[m][n] += X[32m.., s] Y[32n.., s]^T over the 32 samples of the tile, as 2-term split-fp16 products (tt_mfma16.h)
+// with PER-LAUNCH operand scales (powers of two from rigorous magnitude bounds, wg16_scale below): nothing is ever
+// rescaled inside the sample loop, so the persistent accumulators are touched by MFMAs only (per-tile or per-wave
+// "sticky" scales need in-loop arithmetic on the 96-160 accumulator registers, which makes the allocator spill: measured
+// in round 2).  An operand entry v is staged as ONE dword (hi | lo << 16), hi = f16(v sc), lo = f16(v sc - hi), in the
+// same [index][sample] scratch as the fp32 form.  The two halves of a dword are fed to the MFMA as two ADJACENT k-slots:
+// a k-step of 16 slots is 8 samples, slot 2d = hi, slot 2d + 1 = lo of the lane's d-th sample, for both operands -- so
+//     mfma(A, B)          = sum_s (hi_x hi_y + lo_x lo_y)
+//     mfma(A, rot16(B))   = sum_s (hi_x lo_y + lo_x hi_y)
+// together the FULL product of the two split numbers: 8 MFMAs of 32 cycles per 32 x 32 tile instead of 16 fp32 MFMAs of
+// 64, no de-interleaving, one v_alignbit per B dword.  Error per product term <= 2^-22 of the operands' global maxima:
+// fp32-grade for a sum over all samples (the fp32 accumulator itself resolves 2^-24 of the running sum).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 2^(141 - E) for a bound with biased exponent E: maps [0, bound] into the fp16 range (bound -> [2^14, 2^15))
+__device__ __forceinline__ float wg16_scale(float bound) {
+    int E = (int)(__builtin_bit_cast(unsigned, bound * 1.0001f) >> 23) & 0xff;
+    E = E < 16 ? 16 : (E > 240 ? 240 : E);
+    return __builtin_bit_cast(float, (unsigned)(268 - E) << 23);
+}
+__device__ __forceinline__ unsigned wg16_pack(float x) {  // (hi | lo << 16), both round-toward-zero: hi + lo ~ x
+    // (hi by masking the fp32 significand to 11 bits instead of the convert / convert-back pair: same speed, measured)
+    const unsigned p = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, 0.f));
+    const float hf = (float)__builtin_bit_cast(h2_t, p).x;
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, x - hf));
+}
+template <int N>
+__device__ __forceinline__ void stage_rows16(float* S, const float (&v)[N / 2], int j, int hi, float sc) {
+    unsigned* U = reinterpret_cast<unsigned*>(S);
+#pragma unroll
+    for (int r = 0; r < N / 2; ++r) U[LIDX(r, hi) * XS + j] = wg16_pack(v[r] * sc);
+}
+template <int N, int OFF, int TOT>
+__device__ __forceinline__ void stage_rows16_sub(float* S, const float (&v)[TOT], int j, int hi, float sc) {
+    unsigned* U = reinterpret_cast<unsigned*>(S);
+#pragma unroll
+    for (int r = 0; r < N / 2; ++r) U[LIDX(r, hi) * XS + j] = wg16_pack(v[OFF + r] * sc);
+}
+__device__ __forceinline__ h8_t wg16_frag(const float* S, int row, int t, int hi) {
+    return __builtin_bit_cast(h8_t, *reinterpret_cast<const u32x4*>(S + row * XS + 8 * t + 4 * hi));
+}
+__device__ __forceinline__ h8_t wg16_swap(h8_t v) {
+    u32x4 u = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) u[d] = __builtin_amdgcn_alignbit(u[d], u[d], 16);
+    return __builtin_bit_cast(h8_t, u);
+}
+template <int NX, int NY>
+__device__ __forceinline__ void wgrad16(f32x16 (&acc)[NX / 32][NY / 32], const float* Xs, const float* Ys, int i,
+                                        int hi) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // k-step: samples 8 t .. 8 t + 7 (this half-wave: 8 t + 4 hi .. + 3)
+        h8_t xa[NX / 32], yb[NY / 32], ys[NY / 32];
+#pragma unroll
+        for (int m = 0; m < NX / 32; ++m) xa[m] = wg16_frag(Xs, 32 * m + i, t, hi);
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n) {
+            yb[n] = wg16_frag(Ys, 32 * n + i, t, hi);
+            ys[n] = wg16_swap(yb[n]);
+        }
+#pragma unroll
+        for (int m = 0; m < NX / 32; ++m)
+#pragma unroll
+            for (int n = 0; n < NY / 32; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m], yb[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NX / 32; ++m)
+#pragma unroll
+            for (int n = 0; n < NY / 32; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[m], ys[n], acc[m][n], 0, 0, 0);
+    }
+}
+// one 32-row slice of the left operand (see wgrad_row)
+template <int NY>
+__device__ __forceinline__ void wgrad16_row(f32x16 (&acc)[NY / 32], const float* Xs, const float* Ys, int i, int hi) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const h8_t xa = wg16_frag(Xs, i, t, hi);
+        h8_t yb[NY / 32], ys[NY / 32];
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n) {
+            yb[n] = wg16_frag(Ys, 32 * n + i, t, hi);
+            ys[n] = wg16_swap(yb[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, yb[n], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, ys[n], acc[n], 0, 0, 0);
+    }
+}
+
+// workgroup-wide max of a per-thread value through a shared word (all threads call; v >= 0)
+__device__ __forceinline__ float block_max(float v, unsigned* word) {
+    __syncthreads();
+    if (threadIdx.x == 0) *word = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(word, __builtin_bit_cast(unsigned, v));
+    __syncthreads();
+    const float r = __builtin_bit_cast(float, *word);
+    __syncthreads();
+    return r;
+}
+
+// dst += acc * ux * uy  (ux, uy: the inverse operand scales of the fp16 outer products, 1 for the fp32 ones; two
+// factors so that extreme scales cannot overflow their product)
+template <int NX, int NY>
+__device__ __forceinline__ void flush_wgrad(const f32x16 (&acc)[NX / 32][NY / 32], float* __restrict__ dst, int i,
+                                            int hi, float ux = 1.f, float uy = 1.f) {
+#pragma unroll
+    for (int m = 0; m < NX / 32; ++m)
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                atomicAdd(dst + (32 * m + LIDX(r, hi)) * NY + 32 * n + i, (acc[m][n][r] * ux) * uy);
+}
+
+#define ZERO16 \
+    { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }
+
+// ---- plane-gradient scatter, combined on the matrix cores --------------------------------------------------
+// fp32 global atomics are THE bottleneck of the backward on MI355X (~325 G atomic float-adds/s chip-wide,
+// pattern-independent; LDS fp32 atomics are even slower: one ds_add_f32 wave-instruction per ~190 cycles per CU,
+// both measured with tools/atomic_bench.hip / tools/lds_atomic_bench.hip).  A tile is 32 adjacent rays at one
+// depth, so its 128 (sample, corner) references per plane touch only ~40-50 distinct texels.  Per plane the
+// tile's gradient is
+//        G[slot][ch] = sum_j M[slot][j] * Q[j][ch]        (64 texel slots x 32 samples x 32 channels)
+// with M the sparse matrix of corner coefficients -- a GEMM, done exactly in fp32 with 32 MFMAs.  slot = 8x8
+// torus hash of the texel coordinates (the 4 corners of one sample never collide, so M is filled with plain
+// stores); slot ownership is claimed with one integer LDS CAS per reference, and a reference that loses its slot
+// to a different texel (footprint wider than 8 texels) falls back to direct global atomics.  The MFMA C/D layout
+// (lane <-> channel, register <-> slot) is exactly what a coalesced 128-byte global atomic needs, so every
+// occupied slot is flushed with ONE atomic instruction per half-wave straight from the accumulator registers.
+#define MS XS  // row stride of M (floats): same conflict-free stride as the transposition scratch
+
+// M region: either the fp32 matrix (65 rows x MS floats, EXACT) or its split-fp16 image -- two planes (hi, lo) of
+// 65 rows x M16_RS halves (32 samples + pad: 80-byte rows keep the 16-byte A-operand reads spread over the banks)
+#define M16_RS 40
+#define M16_PLANE (65 * M16_RS)
+#define SCATTER_M_FLOATS 2624 /* >= max(65 * MS, 2 * M16_PLANE / 2), multiple of 64 */
+template <bool EXACT>
+__device__ __forceinline__ void scatter_clear(float* M, int lane) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (EXACT) {  // 64 rows of the fp32 matrix (the dump row is never read)
+#pragma unroll
+        for (int g = 0; g < MS / 4; ++g) *reinterpret_cast<f32x4*>(M + lane * MS + 4 * g) = z;
+    } else {
+#pragma unroll
+        for (int g = 0; g < SCATTER_M_FLOATS / 256; ++g) *reinterpret_cast<f32x4*>(M + (g * 64 + lane) * 4) = z;
+        if (lane < (SCATTER_M_FLOATS % 256) / 4)
+            *reinterpret_cast<f32x4*>(M + ((SCATTER_M_FLOATS / 256) * 64 + lane) * 4) = z;
+    }
+}
+
+// The three planes of one tile step, software-pipelined.  Everything except the rare lost-reference path is
+// straight-line code (no per-reference branches: inactive references CAS a per-lane dummy tag and store to a dump
+// row of M; empty slots are dropped by the buffer range check), so that plane p's 32 MFMAs (2048 matrix-pipe cycles,
+// one wave per SIMD: nothing else would fill them) run over plane p+1's corner set-up, slot claims and M fill:
+//   operands of plane p -> registers (A = M rows, B = Q columns) ; M back to zero
+//   prep(p+1) ; GEMM(p) || claim(p+1) ; flush(p) from the accumulators ; tags(p) back to empty
+// Tags are double-buffered (the flush of plane p reads them after plane p+1 claimed its slots).
+// LDS per wave: M = 64 rows + 1 dump row (stride MS), tags = 2 x 64 slots + 32 dummies (SCATTER_TAG_INTS).
+#define SCATTER_TAG_INTS 160
+
+struct PlaneRefs {  // the two corners (2hi, 2hi+1) of this lane's sample in one plane
+    float c0, c1;   // coefficient (0: no reference), normalised per sample unless EXACT
+    int o0, o1;     // absolute texel index (prompt and plane included)
+    int h0, h1;     // slot: 8x8 torus hash of the texel coordinates
+    float qs;       // factor the sample's row of Q must be staged with (inverse of the coefficient normalisation)
+};
+// NORM: the sample's four coefficients are scaled by the power of two that brings the largest into [2^14, 2^15) -- the
+// top of the fp16 range, as tt_mfma16.h does for every split operand -- and the sample's row of Q by its inverse:
+// M Q is unchanged (exactly), column j of M and row j of Q belong to the same sample.
+template <bool NORM>
+__device__ __forceinline__ PlaneRefs plane_refs(const float (&coef)[4], const int (&aoff)[4], const int (&hs)[4],
+                                                int hi) {
+    PlaneRefs r;
+    float cn = 1.f;
+    r.qs = 1.f;
+    if (NORM) {
+        const float m = fmaxf(fmaxf(__builtin_fabsf(coef[0]), __builtin_fabsf(coef[1])),
+                              fmaxf(__builtin_fabsf(coef[2]), __builtin_fabsf(coef[3])));
+        int E = (int)(__builtin_bit_cast(unsigned, m) >> 23);
+        E = E < 16 ? 16 : (E > 240 ? 240 : E);
+        cn = __builtin_bit_cast(float, (unsigned)(268 - E) << 23);    // 2^(141 - E)
+        r.qs = __builtin_bit_cast(float, (unsigned)(E - 14) << 23);   // 1 / cn
+    }
+    r.c0 = (hi ? coef[2] : coef[0]) * cn;
+    r.c1 = (hi ? coef[3] : coef[1]) * cn;
+    r.o0 = hi ? aoff[2] : aoff[0];
+    r.o1 = hi ? aoff[3] : aoff[1];
+    r.h0 = hi ? hs[2] : hs[0];
+    r.h1 = hi ? hs[3] : hs[1];
+    return r;
+}
+struct ClaimState {
+    bool w0, w1;  // wrote M (slot won or shared with the same texel)
+    bool m0, m1;  // won the slot: this lane resets the tag
+    bool l0, l1;  // lost the slot to a different texel: direct atomics
+};
+
+__device__ __forceinline__ void scatter_init_tags(int* tags, int lane) {
+    tags[lane] = -1;
+    tags[64 + lane] = -1;
+    if (lane < 32) tags[128 + lane] = -2;  // dummies: never empty, never equal to a texel index
+}
+
+// store / clear one coefficient of M (column i = this lane's sample; row 64 = dump row)
+template <bool EXACT>
+__device__ __forceinline__ void m_store(float* M, int row, int i, float c) {
+    if (EXACT) {
+        M[row * MS + i] = c;
+    } else {
+        half_t h, l;
+        split16(c, h, l);
+        half_t* Mh = reinterpret_cast<half_t*>(M);
+        Mh[row * M16_RS + i] = h;
+        Mh[M16_PLANE + row * M16_RS + i] = l;
+    }
+}
+template <bool EXACT>
+__device__ __forceinline__ void m_zero(float* M, int row, int i) {
+    if (EXACT) {
+        M[row * MS + i] = 0.f;
+    } else {
+        half_t* Mh = reinterpret_cast<half_t*>(M);
+        Mh[row * M16_RS + i] = (half_t)0.f;
+        Mh[M16_PLANE + row * M16_RS + i] = (half_t)0.f;
+    }
+}
+
+// st (tuning build): per-wave counters [0] active references, [1] lost references, [2] plane-tiles
+template <bool EXACT>
+__device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M, int* tg, int* dummy, int i,
+                                                    unsigned long long* st = nullptr) {
+    ClaimState s;
+    const bool a0 = r.c0 != 0.f, a1 = r.c1 != 0.f;
+    const int old0 = atomicCAS(a0 ? tg + r.h0 : dummy, -1, r.o0);
+    const int old1 = atomicCAS(a1 ? tg + r.h1 : dummy, -1, r.o1);
+    s.m0 = old0 == -1;
+    s.m1 = old1 == -1;
+    s.w0 = tt_eq_either(old0, -1, r.o0);  // won the slot, or it already holds this texel (one compare: tt_device.h)
+    s.w1 = tt_eq_either(old1, -1, r.o1);
+    // not written to M.  (An inactive reference CASes the dummy tag -2, so it is "not written" too; what makes a
+    // reference LOST is a non-zero coefficient on top -- scatter_lost tests the coefficient it selects with this flag,
+    // instead of combining two lane masks here.)
+    s.l0 = !s.w0;
+    s.l1 = !s.w1;
+    m_store<EXACT>(M, s.w0 ? r.h0 : 64, i, r.c0);
+    m_store<EXACT>(M, s.w1 ? r.h1 : 64, i, r.c1);
+#ifdef TT_TUNING
+    if (st) {  // wave-uniform values, flushed once per wave with the phase timers
+        st[0] += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
+        st[1] += __popcll(__ballot((s.l0 ? r.c0 : 0.f) != 0.f)) + __popcll(__ballot((s.l1 ? r.c1 : 0.f) != 0.f));
+        st[2] += 1;
+    }
+#endif
+    return s;
+}
+
+// references that lost their slot (tile footprint wider than the 8x8 window: sparse rays) go straight to global
+// memory, one half-wave per reference (lanes <-> channels: a coalesced 128-byte atomic each)
+__device__ __forceinline__ void scatter_lost(const PlaneRefs& r, const ClaimState& s, const float* Qs, float* Ls,
+                                             __amdgpu_buffer_rsrc_t grsrc, int i, int hi) {
+    const float lc0 = s.l0 ? r.c0 : 0.f, lc1 = s.l1 ? r.c1 : 0.f;  // coefficient of a lost corner, else 0
+    const unsigned long long bal = __ballot(__builtin_fabsf(lc0) + __builtin_fabsf(lc1) != 0.f);
+    if (bal == 0) return;
+    float* Lc = Ls;                                 // [sample][4] coefficient of a lost corner, else 0
+    int* Lo = reinterpret_cast<int*>(Ls + 32 * 4);  // [sample][4] absolute texel index
+    Lc[4 * i + 2 * hi] = lc0;
+    Lc[4 * i + 2 * hi + 1] = lc1;
+    Lo[4 * i + 2 * hi] = r.o0;
+    Lo[4 * i + 2 * hi + 1] = r.o1;
+    // walk only the samples that lost something, two per step (one per half-wave)
+    unsigned todo = (unsigned)(bal & 0xffffffffull) | (unsigned)(bal >> 32);
+    while (todo) {
+        const int s0 = __builtin_ctz(todo);
+        todo &= todo - 1;
+        int s1 = -1;
+        if (todo) {
+            s1 = __builtin_ctz(todo);
+            todo &= todo - 1;
+        }
+        const int sidx2 = hi ? s1 : s0;
+        if (sidx2 >= 0) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(Lc + 4 * sidx2);
+            const i32x4 o4 = *reinterpret_cast<const i32x4*>(Lo + 4 * sidx2);
+            const float v = Qs[sidx2 * 33 + i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned tex = c4[q] != 0.f ? (unsigned)o4[q] : ~0u;  // ~0: beyond num_records, dropped
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v * c4[q], grsrc, (int)((tex << 7) | (4u * (unsigned)i)),
+                                                                0, 0);
+            }
+        }
+    }
+}
+
+// prep(pl, refs): corner set-up of plane pl for this lane's sample (and, where Q differs per plane, its staging into
+// Qs[j*33 + ch] -- the previous plane's B operand is in registers by then).  M: all-zero on entry and on exit.
+// G = M Q for the two 32-slot tiles is either 32 fp32 MFMAs (EXACT, and the texture kernel -- see there; 2048
+// matrix-pipe cycles) or, in the geometry kernel (3.51 -> 3.33 ms), the split-fp16 scheme of tt_mfma16.h: M is already a
+// (hi, lo) fp16 image normalised per sample (plane_refs<true>, m_store), the B operand (16 samples of this lane's
+// channel per half-wave) is normalised per channel and split, and 12 fp16 MFMAs (384 cycles) do the work.
+// prep(pl, refs): corner set-up of plane pl for this lane's sample AND the staging of its row of Q, scaled by refs.qs,
+// into Qs[j*33 + ch] (the previous plane's B operand is in registers by then).  M: all-zero on entry and on exit.
+template <bool EXACT, class Prep>
+__device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigned grad_bytes, const float* Qs, float* M,
+                                               int* tags, float* Ls, int i, int hi, Prep&& prep,
+                                               unsigned long long* st = nullptr) {
+    // BUFFER atomics with a 32-bit BYTE offset (texel << 7 | channel * 4) from the gradient copy: an empty slot's tag
+    // is -1, its offset 0xFFFFFF80 + 4 ch lies beyond num_records (the host refuses gradient buffers of 4 GB - 256 B
+    // and more) and the hardware range check drops the atomic -- no compare, no exec-mask branch per slot (the
+    // predicated global atomics this replaced cost ~100 cycles per slot pair, 12 % of the kernel).
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(grad, 0, (int)grad_bytes, 0x00020000);
+    const unsigned lane_b = 4u * (unsigned)i;
+    int* const dummy = tags + 128 + i;
+    PlaneRefs rc, rn;
+    ClaimState sc, sn;
+    prep(0, rc);
+    sc = scatter_claim<EXACT>(rc, M, tags, dummy, i, st);
+    scatter_lost(rc, sc, Qs, Ls, grsrc, i, hi);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        int* const tg = tags + 64 * (pl & 1);
+        // ---- G = M Q; once its operands are in registers: M back to all-zero, next plane's set-up and Q row; the
+        // next plane's claims fill the matrix-pipe time ----
+        f32x16 acc0 = ZERO16, acc1 = ZERO16;
+        if (EXACT) {
+            f32x4 a4[2][4];
+            float bq[16];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4)
+                    a4[m][t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) bq[t] = Qs[(t + 16 * hi) * 33 + i];
+            M[(sc.w0 ? rc.h0 : 64) * MS + i] = 0.f;
+            M[(sc.w1 ? rc.h1 : 64) * MS + i] = 0.f;
+            if (pl < 2) prep(pl + 1, rn);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0][t >> 2][t & 3], bq[t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1][t >> 2][t & 3], bq[t], acc1, 0, 0, 0);
+            }
+        } else {
+            const half_t* Mh = reinterpret_cast<const half_t*>(M);
+            h8_t ah[2][2], al[2][2];  // [slot tile][k-step]: 8 samples 16 ks + 8 hi .. + 7 of slot row 32 m + i
+            float bs[2][8];           // the same samples of channel i
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const half_t* a = Mh + (32 * m + i) * M16_RS + 16 * ks + 8 * hi;
+                    ah[m][ks] = *reinterpret_cast<const h8_t*>(a);
+                    al[m][ks] = *reinterpret_cast<const h8_t*>(a + M16_PLANE);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bs[ks][j] = Qs[(16 * ks + 8 * hi + j) * 33 + i];
+            m_zero<false>(M, sc.w0 ? rc.h0 : 64, i);
+            m_zero<false>(M, sc.w1 ? rc.h1 : 64, i);
+            if (pl < 2) prep(pl + 1, rn);
+            // per-channel normalisation of the B operand to the top of the fp16 range (column = this lane and lane ^ 32)
+            float mx = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx = fmaxf(mx, __builtin_fabsf(bs[ks][j]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            int E = (int)(__builtin_bit_cast(unsigned, mx) >> 23);
+            E = E < 16 ? 16 : (E > 240 ? 240 : E);
+            const float bsc = __builtin_bit_cast(float, (unsigned)(268 - E) << 23);
+            const float bun = __builtin_bit_cast(float, (unsigned)(E - 14) << 23);
+            h8_t bh[2], bl[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = bs[ks][2 * j] * bsc, x1 = bs[ks][2 * j + 1] * bsc;
+                    const h2_t ph = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+                    const h2_t pq =
+                        __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0 - (float)ph.x, x1 - (float)ph.y));
+                    bh[ks][2 * j] = ph.x;
+                    bh[ks][2 * j + 1] = ph.y;
+                    bl[ks][2 * j] = pq.x;
+                    bl[ks][2 * j + 1] = pq.y;
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][ks], bh[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][ks], bh[ks], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][ks], bl[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][ks], bl[ks], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][ks], bh[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][ks], bh[ks], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0[r] *= bun;
+                acc1[r] *= bun;
+            }
+        }
+        if (pl < 2) sn = scatter_claim<EXACT>(rn, M, tags + 64 * ((pl + 1) & 1), dummy, i, st);
+        // ---- flush: one 128-byte atomic per slot pair, straight from the accumulators (slot of reg 4g+e = LIDX) ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const i32x4 k0 = *reinterpret_cast<const i32x4*>(tg + 8 * g + 4 * hi);
+            const i32x4 k1 = *reinterpret_cast<const i32x4*>(tg + 32 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc0[4 * g + e2], grsrc,
+                                                                (int)(((unsigned)k0[e2] << 7) | lane_b), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc1[4 * g + e2], grsrc,
+                                                                (int)(((unsigned)k1[e2] << 7) | lane_b), 0, 0);
+            }
+        }
+        // ---- tags of this plane back to empty ----
+        *(sc.m0 ? tg + rc.h0 : dummy) = sc.m0 ? -1 : -2;
+        *(sc.m1 ? tg + rc.h1 : dummy) = sc.m1 ? -1 : -2;
+        if (pl < 2) {
+            scatter_lost(rn, sn, Qs, Ls, grsrc, i, hi);
+            rc = rn;
+            sc = sn;
+        }
+    }
+}
+
+struct MlpGradPtrs {
+    float* w1;
+    float* w2;
+    float* w3;
+    float* v1;
+    float* v2;
+    float* v3;
+};
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static inline MlpPtrs to_ptrs(const tt_mlp_weights* w) {
+    MlpPtrs m;
+    m.w1 = w->w1;
+    m.w2 = w->w2;
+    m.w3 = w->w3;
+    m.v1 = w->v1;
+    m.v2 = w->v2;
+    m.v3 = w->v3;
+    return m;
+}
+static inline MlpGradPtrs to_gptrs(const tt_mlp_grads* g) {
+    MlpGradPtrs m;
+    m.w1 = g->w1;
+    m.w2 = g->w2;
+    m.w3 = g->w3;
+    m.v1 = g->v1;
+    m.v2 = g->v2;
+    m.v3 = g->v3;
+    return m;
+}
+
+static inline int debug_flags() {
+#ifdef TT_TUNING
+    const char* e = getenv("TT_DEBUG_FLAGS");  // profiling ablations, tuning build only
+    return e ? (int)strtol(e, nullptr, 0) : 0;
+#else
+    return 0;
+#endif
+}
+
+// the scatter addresses texels with 32-bit byte offsets from the (copy of the) gradient buffer
+static inline bool grad_buffer_too_large(const tt_render_cfg* cfg) {
+    return (long long)cfg->n_prompts * 6 * cfg->plane_h * cfg->plane_w * TT_C * 4 >= (1LL << 32) - 256;
+}
+
+// one 4-wave workgroup per CU (register- and LDS-limited), grid a multiple of 8 (XCD chunking)
+static inline long long persistent_blocks(long long n_items, int cus) {
+    long long blocks = cus;
+    long long need = (n_items + 3) / 4;
+    if (blocks > need) blocks = need;
+    return (blocks + 7) / 8 * 8;
+}
+
+#ifdef TT_TUNING
+extern unsigned long long* g_phase_cycles;  // tt_backward.hip (tuning build only)
+#endif
+// ---- per-launch magnitude bounds for the fp16 outer products (tt_host.h: TT_SLOT_BOUNDS) --------------------------
+// max |x| over flat float4 data, raised into *out with one atomicMax per workgroup (non-negative floats order like their
+// bit patterns; NaN / Inf patterns order above every finite value and end up clamped by wg16_scale).
+static __global__ __launch_bounds__(256) void k_absmax4(const f32x4* __restrict__ x, long long seg4, long long seg_stride4,
+                                                 unsigned* __restrict__ out0, unsigned* __restrict__ out1) {
+    // gridDim.y segments of seg4 float4 elements that start seg_stride4 apart; four independent loads in flight per lane.
+    // out0 <- max |.x| (and, if out1 is null, of the other three components as well); out1 <- max |.y|, |.z|, |.w|
+    const f32x4* seg = x + (long long)blockIdx.y * seg_stride4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    float m0 = 0.f, m1 = 0.f;
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; e + 3 * stride < seg4; e += 4 * stride) {
+        const f32x4 a = seg[e], b = seg[e + stride], c = seg[e + 2 * stride], d = seg[e + 3 * stride];
+        m0 = fmaxf(fmaxf(m0, __builtin_fabsf(a[0])), fmaxf(__builtin_fabsf(b[0]), fmaxf(__builtin_fabsf(c[0]), __builtin_fabsf(d[0]))));
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            m1 = fmaxf(fmaxf(m1, __builtin_fabsf(a[k])), fmaxf(__builtin_fabsf(b[k]), fmaxf(__builtin_fabsf(c[k]), __builtin_fabsf(d[k]))));
+    }
+    for (; e < seg4; e += stride) {
+        const f32x4 v = seg[e];
+        m0 = fmaxf(m0, __builtin_fabsf(v[0]));
+        m1 = fmaxf(m1, fmaxf(__builtin_fabsf(v[1]), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+    }
+    if (!out1) m0 = fmaxf(m0, m1);
+    __shared__ unsigned w[2];
+    if (threadIdx.x < 2) w[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, o));
+        m1 = fmaxf(m1, __shfl_xor(m1, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&w[0], __builtin_bit_cast(unsigned, m0));
+        atomicMax(&w[1], __builtin_bit_cast(unsigned, m1));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(out0, w[0]);
+        if (out1) atomicMax(out1, w[1]);
+    }
+}
+// flat float data of any length (g_rgb: n_rays x 3, g_features: n x 3): scalar loads
+static __global__ __launch_bounds__(256) void k_absmax1(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, __builtin_fabsf(x[e]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ unsigned w;
+    if (threadIdx.x == 0) w = 0u;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) atomicMax(&w, __builtin_bit_cast(unsigned, m));
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, w);
+}
+static inline unsigned absmax_blocks(long long n) {  // ~8 elements per thread, at most 4096 workgroups
+    long long b = (n + 256 * 8 - 1) / (256 * 8);
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+// max |texel| of planes first_plane .. first_plane + 2 of every prompt of the packed buffer
+static inline void launch_planes_bound(const float* packed, const tt_render_cfg& cfg, int first_plane, unsigned* out,
+                                hipStream_t s) {
+    const long long hw4 = (long long)cfg.plane_h * cfg.plane_w * TT_C / 4;  // float4s per plane
+    hipLaunchKernelGGL(k_absmax4, dim3(absmax_blocks(3 * hw4), (unsigned)cfg.n_prompts), dim3(256), 0, s,
+                       reinterpret_cast<const f32x4*>(packed) + first_plane * hw4, 3 * hw4, 6 * hw4, out,
+                       (unsigned*)nullptr);
+}
+
+static inline bool use_wg16(const tt_render_cfg& cfg) { return !(cfg.flags & (TT_R_EXACT_F32 | TT_R_WGRAD_F32)); }
+
+static inline int points_cfg(tt_render_cfg* c, int32_t n_batch, int64_t n_points, int32_t n_prompts,
+                      int32_t views_per_prompt, int32_t plane_h, int32_t plane_w, float radius, float sdf_bias_radius,
+                      int32_t grad_copies, int32_t q_flags) {
+    if (n_batch <= 0 || n_points <= 0 || n_prompts <= 0 || views_per_prompt <= 0) return TT_ERR_BAD_ARG;
+    if ((int64_t)n_prompts * views_per_prompt != n_batch || n_points > 0x7fffffffLL) return TT_ERR_BAD_ARG;
+    c->n_prompts = n_prompts;
+    c->views_per_prompt = views_per_prompt;
+    c->plane_h = plane_h;
+    c->plane_w = plane_w;
+    c->rays_per_view = (int32_t)n_points;
+    c->n_samples = 1;
+    c->n_rays = (int64_t)n_batch * n_points;
+    c->radius = radius;
+    c->sdf_bias_radius = sdf_bias_radius;
+    c->inv_std = 1.f;  // unused by the decode kernels
+    c->cos_anneal_ratio = 1.f;
+    c->rgb_grad_shrink = 1.f;
+    c->flags = (q_flags & TT_Q_EXACT_F32) ? TT_R_EXACT_F32 : 0;
+    c->image_w = 0;
+    c->tile_sb = 1;
+    c->tile_chunk = 0;
+    c->grad_copies = grad_copies;
+    c->skip_eps_tex = 0.f;
+    c->skip_eps_geo = 0.f;
+    return tt_validate_cfg(c);
+}
+
