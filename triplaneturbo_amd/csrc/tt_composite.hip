@@ -387,7 +387,7 @@ extern "C" int tt_eikonal_fwd(const float* sdf_grad, int64_t n, float* loss, voi
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return TT_ERR_LAUNCH;
     long long blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;  // one same-address atomic per workgroup: they serialise at ~11 ns each
     hipLaunchKernelGGL(k_eikonal_fwd, dim3((unsigned)blocks), dim3(256), 0, s, sdf_grad, (long long)n, 1.0 / (double)n, loss);
     return tt_check_launch();
 }
