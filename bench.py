@@ -41,7 +41,9 @@ sys.path.insert(0, ROOT)
 #           algorithmic work, exactly like the recomputed FLOPs).
 # macs:     algorithmic multiply-adds by the pipe that executes them in the default build (recompute and the
 #           scatter-combine GEMM are not counted): "f16x3" = 2-term split-fp16 products (3 x v_mfma_f32_32x32x16_f16 per
-#           32x32x16 tile), "f32" = v_mfma_f32_32x32x2_f32, "valu" = the 64-wide output layers (plain FMAs).
+#           32x32x16 tile), "f16x4" = the weight-gradient outer products (hi|lo pairs as adjacent k-slots: 8 fp16 MFMAs per
+#           32x32x32 tile = 4 MFMA-MACs per algorithmic MAC; on the fp32 MFMA under --wgrad-f32 / --exact-f32),
+#           "f32" = v_mfma_f32_32x32x2_f32, "valu" = the 64-wide output layers (plain FMAs).
 ALG = {
     "tt_render_fwd": {  # k_decode_rays<N,TEX> (+ k_march_fwd): sdf 6208 + feat 10432 + normal chain 6208 = 22848 MAC
         "device_kernel": "k_decode_rays",
@@ -51,25 +53,25 @@ ALG = {
     "tt_render_bwd_geo": {  # (k_march_bwd +) k_decode_bwd_geo: value chain + gradient chain, activations + weights
         "device_kernel": "k_decode_bwd_geo",
         "bytes_8d": 3 * 4 * 32 * 4,
-        "macs": {"f16x3": 2048 + 4096 + 4096 + 2048 + 2048 + 4096, "f32": 2048 + 4096, "valu": 256},
+        "macs": {"f16x3": 2048 + 4096 + 4096 + 2048 + 2048 + 4096, "f16x4": 2048 + 4096, "valu": 256},
     },
     "tt_render_bwd_tex": {  # k_decode_bwd_tex: activations 10432 + weight gradients 10432
         "device_kernel": "k_decode_bwd_tex",
         "bytes_8d": 3 * 4 * 32 * 4,
-        "macs": {"f16x3": 4096 + 6144, "f32": 4096 + 6144, "valu": 384},
+        "macs": {"f16x3": 4096 + 6144, "f16x4": 4096 + 6144, "valu": 384},
     },
 }
 BYTES_MARCH_FWD = 44        # t_starts, t_ends, sdf, sdf_grad(3), features(3) read; weights, trans written
 BYTES_MARCH_BWD = 68        # the 9 above + trans + g_sdf_grad(3) read; (d sdf, d sdf_grad) float4 written
 PEAK_F32_TFLOPS = 157.3     # dense fp32-input MFMA = fp32 vector peak (MI355X_MICROARCH.md): SURVEY 8(d)'s MLP roofline
 PEAK_F16_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
-PEAK = {"f32": PEAK_F32_TFLOPS, "valu": PEAK_F32_TFLOPS, "f16x3": PEAK_F16_TFLOPS / 3.0}
+PEAK = {"f32": PEAK_F32_TFLOPS, "valu": PEAK_F32_TFLOPS, "f16x3": PEAK_F16_TFLOPS / 3.0, "f16x4": PEAK_F16_TFLOPS / 4.0}
 PEAK_HBM_GBS = 8000.0
 DTYPE = "f32 (2xfp16-split products, 22-bit)"
 DTYPE_EXACT = "f32 (fp32-input MFMA)"
 
 
-def kernel_roofline(name, ms, n_samples, exact):
+def kernel_roofline(name, ms, n_samples, exact, wgrad_f32=False):
     """Both forms of  max(algorithmic bytes / HBM peak, algorithmic FLOP / MFMA peak) / measured time :
       frac_8d       SURVEY 8(d) literally: bytes_8d / 8 TB/s against ALL algorithmic FLOP / 157.3 TFLOP/s (the fp32-MFMA
                     roofline 8(d) names).  A value > 1 means the kernel beats both 8(d) ceilings -- possible because the
@@ -77,9 +79,11 @@ def kernel_roofline(name, ms, n_samples, exact):
       frac_pipe_mix the same with every FLOP priced on the pipe that executes it (split-fp16 products: 2500/3 TFLOP/s).
     """
     a = ALG[name]
-    macs = dict(a["macs"])
+    macs = {"f16x3": 0, "f16x4": 0, "f32": 0, "valu": 0, **a["macs"]}
     if exact:  # every matrix product on the fp32 MFMA
-        macs = {"f16x3": 0, "f32": macs["f16x3"] + macs["f32"], "valu": macs["valu"]}
+        macs = {"f16x3": 0, "f16x4": 0, "f32": macs["f16x3"] + macs["f16x4"] + macs["f32"], "valu": macs["valu"]}
+    elif wgrad_f32:  # the round-2 kernels: outer products on the fp32 MFMA
+        macs = {"f16x3": macs["f16x3"], "f16x4": 0, "f32": macs["f16x4"] + macs["f32"], "valu": macs["valu"]}
     flop_per_sample = 2 * sum(macs.values())
     flop = float(flop_per_sample) * n_samples
     t_hbm = a["bytes_8d"] * n_samples / (PEAK_HBM_GBS * 1e9) * 1e3                       # ms at 8 TB/s
@@ -540,8 +544,8 @@ def main():
                 gstep()
             ops.set_kernel_timer(None)
         ksum = timer.summary(median=True)  # label -> (median ms, launches)
-        kernels = {k: dict(kernel_roofline(k, ms, n_samples, args.exact_f32), launches=n) for k, (ms, n) in ksum.items()
-                   if k in ALG}
+        kernels = {k: dict(kernel_roofline(k, ms, n_samples, args.exact_f32, args.wgrad_f32), launches=n)
+                   for k, (ms, n) in ksum.items() if k in ALG}
         traffic, traffic_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_traffic(args.config)
         if traffic:
             for k, v in kernels.items():
