@@ -130,3 +130,30 @@ def test_eval_render_and_field_query_are_bitwise_reproducible():
             continue
         for k in ref:
             assert torch.equal(ref[k], cur[k]), (it, k)
+
+
+def test_gradient_wrt_query_points_is_bitwise_reproducible():
+    """tt_points_bwd_x (d/d query points, incl. the second-order cross derivative) accumulates nothing across lanes: twelve
+    launches on 100 k incoherent points must agree bit for bit (a stale lane mask would show up as per-tile differences,
+    as it did in the per-point forward: tools/stress_export.py)."""
+    import triplaneturbo_amd as tt
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(31)
+    g = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
+    for w_ in g.parameters():
+        w_.requires_grad_(False)  # points only: no atomics anywhere in the backward
+    gen = torch.Generator().manual_seed(32)
+    cache = (torch.randn(1, 6, 32, 128, 128, generator=gen) * 0.5).to(dev)
+    pts = (torch.rand(1, 100_000, 3, generator=gen) * 2.1 - 1.05).to(dev)
+    proj = {k: torch.randn(100_000, c, generator=gen).to(dev) for k, c in (("sdf", 1), ("features", 3), ("sdf_grad", 3))}
+    ref = None
+    for it in range(12):
+        x = pts.clone().requires_grad_(True)
+        out = g(x, cache, output_normal=True)
+        gx, = torch.autograd.grad(sum((out[k] * proj[k]).sum() for k in proj), [x])
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = gx.clone()
+            assert torch.isfinite(ref).all()
+        else:
+            assert torch.equal(ref, gx), (it, (ref != gx).any(-1).nonzero().flatten()[:8].tolist())

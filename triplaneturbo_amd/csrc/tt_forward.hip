@@ -212,7 +212,9 @@ __device__ __forceinline__ void stage_decode_images(float* L, const MlpPtrs& w) 
 }
 
 // 8 waves (2 per SIMD) share one set of split-fp16 weight images (93 KB: one workgroup per CU)
+#ifndef DECODE_THREADS
 #define DECODE_THREADS 512
+#endif
 
 template <bool NEED_N, bool NEED_TEX, bool EXACT>
 __global__ __launch_bounds__(DECODE_THREADS) void k_query_points(QueryParams p) {
