@@ -61,11 +61,11 @@ def _rel(a, b):
 NAMES = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]
 
 
-def _check(g_hip, g32, g64, tol=1e-4):
+def _check(g_hip, g32, g64, tol=1e-4, elem=True):
     """Both bars of tests/parity.py: ||hip - fp32 oracle|| / ||fp32 oracle|| <= 1e-4 (north_star's rtol against the
     fp32 reference math), and as close to the exact fp64 math as the fp32 oracle is."""
     case = os.environ.get("PYTEST_CURRENT_TEST", "test_gpu_backward").split("::")[-1].split(" ")[0]
-    return check_grads(case, g_hip, g32, g64, tol64=tol)
+    return check_grads(case, g_hip, g32, g64, tol64=tol, elem=elem)
 
 
 @pytest.mark.parametrize("exact_f32", [False, True])
@@ -275,3 +275,27 @@ def test_upstream_gradients_of_any_scale(mods, log2_scale):
     for n, a, b in zip(NAMES, g2, g1):
         assert torch.isfinite(a).all(), n
         assert _rel(a, b.double()) < 2e-5, (n, _rel(a, b.double()))
+
+
+@pytest.mark.parametrize("plane_scale", [2.0e3, 1.0e-4])
+def test_planes_of_any_scale(mods, plane_scale):
+    """Per-launch operand scales of the fp16 outer products are derived from max |texel| (tt_backward_common.h): planes
+    far above / below the usual O(1) range must still give oracle-grade gradients (and no fp16 overflow)."""
+    P, R, n_view, Hh, Ww, S, seed = 1, 32, 1, 7, 6, 24, 61
+    g = torch.Generator().manual_seed(seed)
+    cache = torch.randn(P, 6, 32, R, R, generator=g) * 0.5 * plane_scale
+    sw = O.init_mlp_weights([32, 64, 64, 1], g)
+    fw = O.init_mlp_weights([96, 64, 64, 3], g)
+    sw = [sw[0] / plane_scale, sw[1], sw[2]]  # keep the sdf in a sensible range: the surface must still exist
+    ro, rd, c2w, cd = O.make_cameras(P * n_view, Hh, Ww)
+    ts, te = O.uniform_intervals(P * n_view * Hh * Ww, S, 0.3, 3.2)
+    bg = torch.ones(3)
+    proj = {n: torch.randn(P * n_view, Hh, Ww, c, generator=g) for n, c in KEYS}
+    rck = dict(inv_std=40.0, rgb_grad_shrink=1.0, cos_anneal_ratio=1.0)
+    _, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    _, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    _, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    assert all(torch.isfinite(t).all() for t in g_hip)
+    # norm bars only: a 42-ray scene leaves a handful of elements above the atol floor of the 192-element matrices, too
+    # few for the violating-fraction form of the element-wise bar (the numbers still land in the parity report)
+    _check(g_hip, g32, g64, elem=False)
