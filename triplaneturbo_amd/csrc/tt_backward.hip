@@ -274,8 +274,11 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         for (int k = 0; k < 20; ++k) atomicAdd(p.phase_cycles + 20 + k, ph_acc[k]);
 #endif
     // ---- flush the persistent weight-gradient accumulators ----
-    flush_wgrad<64, 32>(accW1, p.grads.w1, i, hi, 1.f / sA1, 1.f / sU);
-    flush_wgrad<64, 64>(accW2, p.grads.w2, i, hi, 1.f / sA2, 1.f / sV);
+    // (summed over the workgroup's four waves first: the weight images in LDS are dead by now)
+    __syncthreads();
+    int parity = 0;
+    flush_wgrad_reduced<64, 32>(L, parity, accW1, p.grads.w1, wave_in_blk, lane, 1.f / sA1, 1.f / sU);
+    flush_wgrad_reduced<64, 64>(L, parity, accW2, p.grads.w2, wave_in_blk, lane, 1.f / sA2, 1.f / sV);
     atomicAdd(p.grads.w3 + lane, accw3);
 }
 

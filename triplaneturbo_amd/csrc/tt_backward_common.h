@@ -213,6 +213,38 @@ __device__ __forceinline__ void flush_wgrad(const f32x16 (&acc)[NX / 32][NY / 32
                 atomicAdd(dst + (32 * m + LIDX(r, hi)) * NY + 32 * n + i, (acc[m][n][r] * ux) * uy);
 }
 
+// Workgroup pre-reduction of one 32 x 32 accumulator tile at kernel end: the four waves' copies are summed through LDS
+// (R: 2 x 4096 floats, alternating by `parity` so that one barrier per tile is enough) and wave w adds registers
+// 4 w .. 4 w + 3 of the sum to memory -- a quarter of the same-address float atomics, which serialise at the memory side
+// (~1 000 waves add into the same 66 KB).  All 256 threads call it, in the same order, after the main loop.
+template <class Addr>
+__device__ __forceinline__ void flush_tile_reduced(float* R, int parity, const f32x16& acc, int wave, int lane,
+                                                   float ux, float uy, Addr addr) {
+    float* B = R + parity * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) B[(wave * 16 + r) * 64 + lane] = (acc[r] * ux) * uy;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * wave + q;
+        const float v = (B[r * 64 + lane] + B[(16 + r) * 64 + lane]) + (B[(32 + r) * 64 + lane] + B[(48 + r) * 64 + lane]);
+        atomicAdd(addr(r), v);
+    }
+}
+template <int NX, int NY>
+__device__ __forceinline__ void flush_wgrad_reduced(float* R, int& parity, const f32x16 (&acc)[NX / 32][NY / 32],
+                                                    float* __restrict__ dst, int wave, int lane, float ux, float uy) {
+    const int i = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < NX / 32; ++m)
+#pragma unroll
+        for (int n = 0; n < NY / 32; ++n) {
+            flush_tile_reduced(R, parity, acc[m][n], wave, lane, ux, uy,
+                               [&](int r) { return dst + (32 * m + LIDX(r, hi)) * NY + 32 * n + i; });
+            parity ^= 1;
+        }
+}
+
 #define ZERO16 \
     { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }
 

@@ -330,18 +330,27 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     if (p.phase_cycles && lane == 0)
         for (int k = 0; k < 20; ++k) atomicAdd(p.phase_cycles + k, ph_acc[k]);
 #endif
-    // dV1 is (64, 96) row-major: columns 0..63 from accV1a, 64..95 from accV1b
+    // dV1 is (64, 96) row-major: columns 0..63 from accV1a, 64..95 from accV1b.  Every matrix is summed over the
+    // workgroup's four waves first (the weight images in LDS are dead by now)
+    __syncthreads();
+    int parity = 0;
+    {
+        const float u1 = 1.f / sKB1, u2 = 1.f / sE;  // inverse operand scales (1 for the fp32 outer products)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * m + LIDX(r, hi);
-            const float u1 = 1.f / sKB1, u2 = 1.f / sE;  // inverse operand scales (1 for the fp32 outer products)
-            atomicAdd(p.grads.v1 + row * 96 + i, (accV1a[m][0][r] * u1) * u2);
-            atomicAdd(p.grads.v1 + row * 96 + 32 + i, (accV1a[m][1][r] * u1) * u2);
-            atomicAdd(p.grads.v1 + row * 96 + 64 + i, (accV1b[m][0][r] * u1) * u2);
+        for (int m = 0; m < 2; ++m) {
+            float* const base = p.grads.v1 + (32 * m) * 96 + i;
+            flush_tile_reduced(Lt, parity, accV1a[m][0], wave_in_blk, lane, u1, u2,
+                               [&](int r) { return base + LIDX(r, hi) * 96; });
+            parity ^= 1;
+            flush_tile_reduced(Lt, parity, accV1a[m][1], wave_in_blk, lane, u1, u2,
+                               [&](int r) { return base + LIDX(r, hi) * 96 + 32; });
+            parity ^= 1;
+            flush_tile_reduced(Lt, parity, accV1b[m][0], wave_in_blk, lane, u1, u2,
+                               [&](int r) { return base + LIDX(r, hi) * 96 + 64; });
+            parity ^= 1;
         }
-    flush_wgrad<64, 64>(accV2, p.grads.v2, i, hi, 1.f / sK2B, 1.f / sK1);
+    }
+    flush_wgrad_reduced<64, 64>(Lt, parity, accV2, p.grads.v2, wave_in_blk, lane, 1.f / sK2B, 1.f / sK1);
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
