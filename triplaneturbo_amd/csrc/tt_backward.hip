@@ -179,10 +179,22 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
             }
-            mvtx<EXACT, 64, 64>(L + GOFF_W2T, L + OFF_W2, a2, a1, i, hi);
+            // a2 and a1 feed a product AND an outer product (dW2, dW1): split once under the per-launch scales
+            Split16<64> a2s, a1s;
+            if (WG16) {
+                split16_vec<64>(a2, sA2, a2s);
+                mv16_pre<64, 64>(L + GOFF_W2T, a2s, 1.f / sA2, a1, i, hi);
+            } else {
+                mvtx<EXACT, 64, 64>(L + GOFF_W2T, L + OFF_W2, a2, a1, i, hi);
+            }
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-            mvtx<EXACT, 32, 64>(L + GOFF_W1T, L + OFF_W1, a1, q, i, hi);
+            if (WG16) {
+                split16_vec<64>(a1, sA1, a1s);
+                mv16_pre<32, 64>(L + GOFF_W1T, a1s, 1.f / sA1, q, i, hi);
+            } else {
+                mvtx<EXACT, 32, 64>(L + GOFF_W1T, L + OFF_W1, a1, q, i, hi);
+            }
             TT_PHASE(3);
             // ---- network + plane gradients ----
             {
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 // dW1 += a1 (sbar f + qbar)^T
                 if (do_wgrad) {
                     if (WG16) {
-                        stage_rows16<64>(Xs, a1, i, hi, sA1);
+                        stage_rows16_pre<64>(Xs, a1s, i, hi);
                         stage_rows16<32>(Ys, u, i, hi, sU);
                         wgrad16<64, 32>(accW1, Xs, Ys, i, hi);
                     } else {
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 // dW2 += a2 v^T
                 if (do_wgrad) {
                     if (WG16) {
-                        stage_rows16<64>(Xs, a2, i, hi, sA2);
+                        stage_rows16_pre<64>(Xs, a2s, i, hi);
                         stage_rows16<64>(Ys, v, i, hi, sV);
                         wgrad16<64, 64>(accW2, Xs, Ys, i, hi);
                     } else {

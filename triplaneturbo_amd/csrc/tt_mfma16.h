@@ -146,6 +146,65 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
         for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k] * un;
 }
 
+// ---- operands split ONCE per vector, with a scale known before the launch --------------------------------------------
+// A vector that is both the input of a mat-vec product and one side of a weight-gradient outer product (which needs one
+// scale for ALL samples: tt_backward_common.h) is split once under that per-launch scale: hi / lo pairs in the k-slot
+// order of mv16, from which the outer product's (hi | lo << 16) dwords are one v_perm each.  Used for vectors whose
+// magnitude does not depend on the sample's upstream gradient (activations, masked weight products): their bound is within
+// a few binades of every sample's own maximum, so the per-launch scale loses nothing against the per-sample one.
+template <int N>
+struct Split16 {
+    unsigned h[N / 4], l[N / 4];  // pair t <-> registers 2 t, 2 t + 1 of the LIDX layout: (f16 hi | f16 hi' << 16), same for lo
+};
+template <int N>
+__device__ __forceinline__ void split16_vec(const float (&x)[N / 2], float sc, Split16<N>& o) {
+#pragma unroll
+    for (int t = 0; t < N / 4; ++t) {
+        const f2_t ab = {x[2 * t], x[2 * t + 1]};
+        const f2_t as = ab * sc;  // exact (power of two)
+        const unsigned pu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(as.x, as.y));
+        const h2_t p = __builtin_bit_cast(h2_t, pu);
+        const float ra = as.x - (float)p.x, rb = as.y - (float)p.y;  // exact residuals
+        o.h[t] = pu;
+        o.l[t] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+    }
+}
+// mv16 on a pre-split operand: y = M x with x = (hi + lo) * un_x
+template <int NOUT, int NIN>
+__device__ __forceinline__ void mv16_pre(const float* img_f, const Split16<NIN>& x, float un_x, float (&y)[NOUT / 2],
+                                         int i, int hi) {
+    constexpr int MT = NOUT / 32, KS = NIN / 16, RS = 2 * NIN + 8;
+    const half_t* row = reinterpret_cast<const half_t*>(img_f) + (size_t)i * RS + 8 * hi;
+    const float un = img_f[(size_t)i * (NIN + 4) + NIN] * un_x;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        acc[m] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const h8_t bh = __builtin_bit_cast(h8_t, u4_t{x.h[4 * s], x.h[4 * s + 1], x.h[4 * s + 2], x.h[4 * s + 3]});
+        const h8_t bl = __builtin_bit_cast(h8_t, u4_t{x.l[4 * s], x.l[4 * s + 1], x.l[4 * s + 2], x.l[4 * s + 3]});
+        h8_t ah[MT], al[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const half_t* a = row + (size_t)(32 * m) * RS + 32 * s;
+            ah[m] = *reinterpret_cast<const h8_t*>(a);
+            al[m] = *reinterpret_cast<const h8_t*>(a + 16);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k] * un;
+}
+
 // ---- precision switch ----------------------------------------------------------------------------------------------
 // EXACT = true (cfg.flags & TT_R_EXACT_F32): every matrix product on v_mfma_f32_32x32x2_f32 (bit-for-bit a k-ordered
 // fmaf chain, 1/16 of the fp16 pipe's rate) from plain fp32 weight images -- the A/B reference for the split-fp16
