@@ -199,15 +199,18 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         const bool region = cfg.flags >= 0;
         const bool region_w = WG16 ? true : region;
         const bool do_wgrad = region_w && !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
-        if (do_wgrad) {
-            if (WG16)
-                stage_rows16<96>(Ys, e, i, hi, sE);
-            else
-                stage_rows<96>(Ys, e, i, hi);
-        }
-        TT_PHASE(2);
         float k1[32], k2[32];
-        mvx<EXACT, 64, 96>(Lt + TV1, e, k1, i, hi);
+        if (WG16) {  // e is split once, under its per-launch scale, for the outer product and for V1 e
+            Split16<96> es;
+            split16_vec<96>(e, sE, es);
+            if (do_wgrad) stage_rows16_pre<96>(Ys, es, i, hi);
+            TT_PHASE(2);
+            mv16_pre<64, 96>(Lt + TV1, es, 1.f / sE, k1, i, hi);
+        } else {
+            if (do_wgrad) stage_rows<96>(Ys, e, i, hi);
+            TT_PHASE(2);
+            mvx<EXACT, 64, 96>(Lt + TV1, e, k1, i, hi);
+        }
 #pragma unroll
         for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
         TT_PHASE(3);
