@@ -214,7 +214,13 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
 #pragma unroll
         for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
         TT_PHASE(3);
-        mvx<EXACT, 64, 64>(Lt + TV2, k1, k2, i, hi);
+        Split16<64> k1s;  // k1 likewise: V2 k1 now, the dV2 outer product later
+        if (WG16) {
+            split16_vec<64>(k1, sK1, k1s);
+            mv16_pre<64, 64>(Lt + TV2, k1s, 1.f / sK1, k2, i, hi);
+        } else {
+            mvx<EXACT, 64, 64>(Lt + TV2, k1, k2, i, hi);
+        }
 #pragma unroll
         for (int r = 0; r < 32; ++r) k2[r] = fmaxf(k2[r], 0.f);
         TT_PHASE(4);
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             // ---- dV2 += k2bar k1^T  (e is dead: k2bar in rows 0..63, k1 in rows 64..127) ----
             if (WG16) {
                 stage_rows16<64>(Xs, k2, i, hi, sK2B);
-                stage_rows16<64>(Xs + 64 * XS, k1, i, hi, sK1);
+                stage_rows16_pre<64>(Xs + 64 * XS, k1s, i, hi);
                 wgrad16<64, 64>(accV2, Xs, Xs + 64 * XS, i, hi);
             } else {
                 stage_rows<64>(Xs, k2, i, hi);
