@@ -66,15 +66,12 @@ lib.tt_tuning_phase_cycles(buf)
 names = ["upstream cbar + skip test", "gather e (12 corners)", "park e in LDS", "k1 = relu(V1 e)", "k2 = relu(V2 k1)",
          "dV3 (transpose + VALU)", "k2bar, k1bar = V2^T k2bar", "dV1 outer products", "dV2 outer products",
          "ebar_p = V1_p^T k1bar + stage (x3)", "scatter_plane epilogue", "tail",
-         "  scatter: slot claims (LDS CAS) + M fill", "  scatter: combine GEMM M Q (fp32 MFMA)",
-         "  scatter: flush (predicated 128-byte atomics)", "  scatter: restore M / tags", "  scatter: lost-reference fallback",
+         "", "", "", "", "",  # (slots 12..16 carry the live-lane / scatter statistics printed above)
          "end of tile step -> pop", "item pop (queue atomic)", "ray set-up (issue)"]
 geo_names = ["upstream (d sdf, d sdf_grad) + skip test", "gather f, u (12 corners)", "", "sdf net recompute + reverse chain (5 products)",
              "a1bar = W1 qbar, v", "a2bar = W2 b1bar, dw3 (transpose + VALU)", "", "dW1 outer products",
              "dW2 outer products", "scatter: q staging + corner set-up", "scatter epilogue", "tail",
-             "  scatter: slot claims (LDS CAS) + M fill", "  scatter: combine GEMM M Q (fp32 MFMA)",
-             "  scatter: flush (predicated 128-byte atomics)", "  scatter: restore M / tags",
-             "  scatter: lost-reference fallback", "", "", ""]
+             "", "", "", "", "", "", "", ""]
 print(f"texture backward: {buf[12] / n / 1024:.0f} live tile steps per wave per launch, {buf[13] / max(buf[12], 1):.1f} of 32 lanes live on average, {buf[14] / max(buf[12], 1):.1f} with |cbar| > 1e-12")
 tex_pt, geo_pt = 3 * buf[12], buf[36]
 print(f"scatter, texture kernel: {buf[15] / max(tex_pt, 1):.1f} active references per plane-tile, "
