@@ -204,11 +204,6 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 // (no opaque scheduling region here, unlike the texture kernel: with the outer products on the fp16 pipe
                 // this kernel has register slack and one scheduling region is faster: 3.22 -> 3.14 ms)
                 const bool region = WG16 ? true : cfg.flags >= 0;  // (always true; opaque to the compiler unless WG16)
-#ifdef TT_X_GEO_REGION_SCATTER
-                const bool region_s = cfg.flags >= 0;
-#else
-                const bool region_s = region;
-#endif
                 const bool do_wgrad = region && !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
                 // dW1 += a1 (sbar f + qbar)^T
                 if (do_wgrad) {
@@ -254,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 accw3 += rowsum32(Xs, lane);
                 TT_PHASE(5);
                 // ---- scatter d/d geometry planes: texel(p,c)[ch] += q[ch] * coef(p,c) ----
-                if (region_s && !TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
+                if (region && !TT_DBG(cfg.flags, TT_DBG_NO_SCATTER)) {
                     scatter_clear<EXACT>(Xs, lane);  // M = 0 (Xs held wgrad staging; SCATTER_M_FLOATS reach into Ys)
                     float* Qs = Xs + SCATTER_M_FLOATS;  // the sample's row of Q: q scaled per plane, stride 33
                     TT_PHASE(9);
