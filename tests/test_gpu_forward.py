@@ -33,15 +33,24 @@ def _scene(seed, P, R, n_view, Hh, Ww, S, near=0.1, far=4.0, scale=0.5):
     return cache, sw, fw, ro, rd, c2w, cd, ts, te
 
 
-def test_planes_pack_is_rotate_v1_channels_last(ops):
+@pytest.mark.parametrize("R", [16, 18, 48, 52, 256])  # 18: the scalar kernel (W % 4 != 0); 52: row stride padding
+def test_planes_pack_is_rotate_v1_channels_last(ops, R):
     g = torch.Generator().manual_seed(0)
-    cache = torch.randn(2, 6, 32, 16, 16, generator=g)
+    cache = torch.randn(2, 6, 32, R, R, generator=g)
     packed = ops.planes_pack(cache.cuda()).cpu()
     want = O.rotate_planes_v1(cache).permute(0, 1, 3, 4, 2).contiguous()
     assert torch.equal(packed, want)
     # unpack_grad is the exact transpose (a permutation): round trip is the identity
     back = ops.planes_unpack_grad(packed.cuda()).cpu()
     assert torch.equal(back, cache)
+
+
+def test_planes_unpack_grad_sums_the_privatised_copies(ops):
+    g = torch.Generator().manual_seed(1)
+    copies = torch.randn(3, 1, 6, 24, 24, 32, generator=g)
+    got = ops.planes_unpack_grad(copies.cuda()).cpu()  # 6-d input: (copies, P, 6, H, W, 32)
+    one = [ops.planes_unpack_grad(copies[k].contiguous().cuda()).cpu() for k in range(3)]
+    torch.testing.assert_close(got, (one[0] + one[1]) + one[2], rtol=0, atol=0)
 
 
 def test_query_points_matches_reference_golden(ops, golden_dir):

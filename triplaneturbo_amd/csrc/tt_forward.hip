@@ -66,6 +66,62 @@ __global__ __launch_bounds__(256) void k_planes_pack(const float* __restrict__ s
     }
 }
 
+// The same for W % 4 == 0 (every size the reference uses): 16-byte accesses on the NCHW side and on both LDS sides (a
+// quarter of the instructions), whole 128-byte texel lines per half-wave on the channels-last side.  tile = [32][RS],
+// RS = W + pad with RS = 4 (mod 32): the 16-byte LDS reads of 8 consecutive channel rows then cover all 32 banks.
+__host__ __device__ inline int pack4_row_stride(int W) { return W + (36 - W % 32) % 32; }
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void k_planes_pack4(const float* __restrict__ src, float* __restrict__ dst, int H,
+                                                      int W, int n_copies, size_t copy_stride) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [32][RS]
+    const int y = blockIdx.x, plane = blockIdx.y;  // plane = p*6 + k
+    const int k3 = plane % 3;
+    const size_t HW = (size_t)H * W;
+    const float* nchw_c = (UNPACK ? dst : src) + (size_t)plane * TT_C * HW + (size_t)y * W;
+    float* nchw = const_cast<float*>(nchw_c);
+    const float* nhwc_c = (UNPACK ? src : dst) + (size_t)plane * HW * TT_C;
+    float* nhwc = const_cast<float*>(nhwc_c);
+    const int RS = pack4_row_stride(W), W4 = W >> 2;
+    const int c_lane = threadIdx.x & 31, x4_0 = threadIdx.x >> 5;
+    if (!UNPACK) {
+        for (int e4 = threadIdx.x; e4 < TT_C * W4; e4 += 256) {
+            const int c = e4 / W4, x4 = e4 - c * W4;
+            *reinterpret_cast<f32x4*>(tile + c * RS + 4 * x4) =
+                *reinterpret_cast<const f32x4*>(nchw_c + (size_t)c * HW + 4 * x4);
+        }
+        __syncthreads();
+        for (int x4 = x4_0; x4 < W4; x4 += 8) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + c_lane * RS + 4 * x4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int h, w;
+                rot_dst(k3, y, 4 * x4 + j, H, W, h, w);
+                nhwc[((size_t)h * W + w) * TT_C + c_lane] = v[j];
+            }
+        }
+    } else {
+        for (int x4 = x4_0; x4 < W4; x4 += 8) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int h, w;
+                rot_dst(k3, y, 4 * x4 + j, H, W, h, w);
+                const size_t o = ((size_t)h * W + w) * TT_C + c_lane;
+                float acc = nhwc_c[o];
+                for (int k = 1; k < n_copies; ++k) acc += nhwc_c[o + (size_t)k * copy_stride];
+                v[j] = acc;
+            }
+            *reinterpret_cast<f32x4*>(tile + c_lane * RS + 4 * x4) = v;
+        }
+        __syncthreads();
+        for (int e4 = threadIdx.x; e4 < TT_C * W4; e4 += 256) {
+            const int c = e4 / W4, x4 = e4 - c * W4;
+            *reinterpret_cast<f32x4*>(nchw + (size_t)c * HW + 4 * x4) =
+                *reinterpret_cast<const f32x4*>(tile + c * RS + 4 * x4);
+        }
+    }
+}
+
 // =====================================================================================================
 // per-tile decode (forward): gather -> sdf net (+ input-gradient chain) -> feature net
 // =====================================================================================================
@@ -583,9 +639,15 @@ extern "C" int tt_planes_pack(const float* space_cache, float* packed, int32_t n
     if (!space_cache || !packed || n_prompts <= 0 || plane_h <= 0 || plane_w <= 0) return TT_ERR_BAD_ARG;
     if (plane_h != plane_w) return TT_ERR_UNSUPPORTED;
     dim3 grid(plane_h, n_prompts * 6);
-    size_t lds = (size_t)TT_C * (plane_w + 1) * sizeof(float);
-    hipLaunchKernelGGL(k_planes_pack<false>, grid, dim3(256), lds, (hipStream_t)stream, space_cache, packed, plane_h,
-                       plane_w, 1, (size_t)0);
+    if (plane_w % 4 == 0 && ((uintptr_t)space_cache & 15) == 0) {
+        size_t lds = (size_t)TT_C * pack4_row_stride(plane_w) * sizeof(float);
+        hipLaunchKernelGGL(k_planes_pack4<false>, grid, dim3(256), lds, (hipStream_t)stream, space_cache, packed,
+                           plane_h, plane_w, 1, (size_t)0);
+    } else {
+        size_t lds = (size_t)TT_C * (plane_w + 1) * sizeof(float);
+        hipLaunchKernelGGL(k_planes_pack<false>, grid, dim3(256), lds, (hipStream_t)stream, space_cache, packed,
+                           plane_h, plane_w, 1, (size_t)0);
+    }
     return tt_check_launch();
 }
 
@@ -595,9 +657,16 @@ extern "C" int tt_planes_unpack_grad(const float* grad_packed, float* grad_space
         return TT_ERR_BAD_ARG;
     if (plane_h != plane_w) return TT_ERR_UNSUPPORTED;
     dim3 grid(plane_h, n_prompts * 6);
-    size_t lds = (size_t)TT_C * (plane_w + 1) * sizeof(float);
-    hipLaunchKernelGGL(k_planes_pack<true>, grid, dim3(256), lds, (hipStream_t)stream, grad_packed, grad_space_cache,
-                       plane_h, plane_w, n_copies, (size_t)n_prompts * 6 * plane_h * plane_w * TT_C);
+    const size_t copy_stride = (size_t)n_prompts * 6 * plane_h * plane_w * TT_C;
+    if (plane_w % 4 == 0 && ((uintptr_t)grad_space_cache & 15) == 0) {
+        size_t lds = (size_t)TT_C * pack4_row_stride(plane_w) * sizeof(float);
+        hipLaunchKernelGGL(k_planes_pack4<true>, grid, dim3(256), lds, (hipStream_t)stream, grad_packed,
+                           grad_space_cache, plane_h, plane_w, n_copies, copy_stride);
+    } else {
+        size_t lds = (size_t)TT_C * (plane_w + 1) * sizeof(float);
+        hipLaunchKernelGGL(k_planes_pack<true>, grid, dim3(256), lds, (hipStream_t)stream, grad_packed,
+                           grad_space_cache, plane_h, plane_w, n_copies, copy_stride);
+    }
     return tt_check_launch();
 }
 
