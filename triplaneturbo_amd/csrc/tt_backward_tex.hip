@@ -421,7 +421,7 @@ extern "C" int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, c
     p.grad_packed = grad_packed;
     p.n_copies = cfg->grad_copies > 0 ? cfg->grad_copies : 1;
     p.grads = to_gptrs(grads);
-    p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom, 1);
+    p.n_items = tt_make_geom(cfg, 4LL * cus, &p.geom, 1, 12);
     long long blocks = persistent_blocks(p.n_items, cus);
     if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
     p.queue = tt_queue_counters((hipStream_t)stream);

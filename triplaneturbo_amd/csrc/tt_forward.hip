@@ -742,7 +742,8 @@ int tt_validate_cfg(const tt_render_cfg* cfg) {
 
 // Fills the tile geometry and picks the chunk length: enough items (>= 8 per wave slot) for balance, chunks as
 // long as possible so consecutive depths of the same rays reuse L1/L2-resident texels.
-long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g, int default_order) {
+long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g, int default_order,
+                       int steps_per_item) {
     g->n_rays = cfg->n_rays;
     g->rays_per_view = cfg->rays_per_view;
     g->n_samples = cfg->n_samples;
@@ -774,9 +775,10 @@ long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom*
         n_blocks = (cfg->n_rays + rb - 1) / rb;
     }
     const int n_steps = (cfg->n_samples + sb - 1) / sb;
-    // ~6 tile steps per item (measured sweet spot of the dynamic queue: per-item ray setup + one pop amortised,
-    // items fine enough that the last ones finish together), but at least 8 items per wave slot
-    int n_chunks = (n_steps + 5) / 6;
+    // ~6 (geometry backward) / ~12 (forward, texture backward) tile steps per item -- the measured sweet spots of the
+    // dynamic queue: per-item ray setup + one pop amortised, items fine enough that the last ones finish together -- but
+    // at least 8 items per wave slot
+    int n_chunks = (n_steps + steps_per_item - 1) / steps_per_item;
     const int min_chunks = (int)((8 * wave_slots + n_blocks - 1) / n_blocks);
     if (n_chunks < min_chunks) n_chunks = min_chunks;
     if (n_chunks < 1) n_chunks = 1;
@@ -844,7 +846,7 @@ extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const
     p.sdf_grad = sdf_grad;
     p.features = features;
     const long long slots = (long long)cus * (DECODE_THREADS / 64);  // one 8-wave workgroup per CU (LDS 93 KB)
-    p.n_items = tt_make_geom(cfg, slots, &p.geom, 1);
+    p.n_items = tt_make_geom(cfg, slots, &p.geom, 1, 12);
     long long blocks = cus;
     long long need = (p.n_items + 7) / 8;
     if (blocks > need) blocks = need;
@@ -890,7 +892,7 @@ extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, cons
     p.sdf_grad = sdf_grad;
     p.features = features;
     const long long slots = (long long)cus * (DECODE_THREADS / 64);
-    p.n_items = tt_make_geom(cfg, slots, &p.geom, 1);
+    p.n_items = tt_make_geom(cfg, slots, &p.geom, 1, 12);
     long long blocks = cus;
     long long need = (p.n_items + 7) / 8;
     if (blocks > need) blocks = need;
