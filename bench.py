@@ -388,6 +388,7 @@ def main():
     ap.add_argument("--lib-variant", default=None, help=argparse.SUPPRESS)  # dev A/B: an experiment build of the library
     ap.add_argument("--tile-sb", type=int, default=0, help=argparse.SUPPRESS)      # dev sweeps of the performance knobs
     ap.add_argument("--tile-chunk", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--grad-copies", type=int, default=1, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
@@ -430,7 +431,7 @@ def main():
     inp = make_inputs(rank, world, device, args.config, R, Hh, Ww, S)
     P = inp["cache"].shape[0]
     rc = ops.RenderConfig(exact_f32=args.exact_f32, wgrad_f32=args.wgrad_f32, tile_sb=args.tile_sb,
-                          tile_chunk=args.tile_chunk)
+                          tile_chunk=args.tile_chunk, grad_copies=args.grad_copies)
     bucket = FlatGradBucket(inp["sw"] + inp["fw"])  # MLP grads = views of one buffer: one collective, no cat / copies
     fused = not args.torch_loss
 
