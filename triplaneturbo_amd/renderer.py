@@ -136,7 +136,8 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         # comp_rgb < 2 eps, of depth < eps * far, of z_variance / comp_normal likewise O(eps) (measured at eps = 1e-4 on
         # the bench scene: opacity 1.0e-4, depth 1.7e-4, 17 % fewer geometry tile steps).
         # Default 0 = march every sample like the reference (renderer :317-324): a validation image rendered through
-        # the plugin equals the reference's.  Not a reference knob, so not in Config.
+        # the plugin equals the reference's (it then runs on the training forward kernels, which are faster than the
+        # fused kernel when nothing may be skipped: functional.volume_render).  Not a reference knob, so not in Config.
         self.eval_termination_eps = 0.0
 
     # ------------------------------------------------------------------------------------------
