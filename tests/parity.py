@@ -57,8 +57,10 @@ def report(case, rows):
         pass
 
 
-def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-4, elem=True):
-    """g_*: lists of tensors (HIP, fp32 oracle, fp64 oracle) in the order of `names`."""
+def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-4, elem=True, noise32=0.0):
+    """g_*: lists of tensors (HIP, fp32 oracle, fp64 oracle) in the order of `names`.  noise32 > 0 (fuzzed, possibly
+    ill-conditioned scenes only): the direct HIP-vs-fp32 bar is widened to noise32 x the fp32 oracle's own distance from
+    fp64 where that is larger -- two fp32 evaluations cannot agree better than either agrees with the exact result."""
     rows = {}
     for n, a, b32, b64 in zip(names, g_hip, g32, g64):
         rows[n] = {"hip_vs_fp32": rel(a, b32), "hip_vs_fp64": rel(a, b64), "fp32_vs_fp64": rel(b32, b64),
@@ -66,7 +68,7 @@ def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-
                    "elem_fp32_vs_fp64": elementwise(b32, b64)}
     report(case, rows)
     for n, r in rows.items():
-        assert r["hip_vs_fp32"] <= tol32, (case, n, rows)
+        assert r["hip_vs_fp32"] <= max(tol32, noise32 * r["fp32_vs_fp64"]), (case, n, rows)
         assert r["hip_vs_fp64"] <= max(tol64, 3 * r["fp32_vs_fp64"]), (case, n, rows)
         if elem:
             assert r["elem_hip_vs_fp64"]["viol_frac"] <= ELEM_SLACK * r["elem_fp32_vs_fp64"]["viol_frac"] + ELEM_FLOOR, \

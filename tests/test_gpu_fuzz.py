@@ -1,0 +1,60 @@
+"""Seeded fuzz of the training render: random plane sizes, ray grids, sample counts, tilings, variance / shrink / anneal
+values, stratified (non-uniform) intervals and precision modes -- forward outputs and every gradient against the fp32 /
+fp64 CPU oracle at the bars of tests/parity.py (norm bars: the scenes are too small for the statistical element-wise bar)."""
+import random
+
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+from parity import check_grads, check_outputs
+from test_gpu_backward import KEYS, _hip_grads, _oracle_grads, mods  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rnd = random.Random(1000 + seed)
+    P = rnd.choice([1, 1, 2, 3])
+    n_view = rnd.choice([1, 2, 3])
+    R = rnd.choice([8, 12, 20, 32, 36, 64])
+    Hh, Ww = rnd.randint(1, 9), rnd.randint(1, 11)
+    S = rnd.choice([1, 2, 7, 16, 31, 32, 33, 50, 64])
+    rc = dict(inv_std=rnd.choice([1.0, 10.0, 40.0, 100.0]), rgb_grad_shrink=rnd.choice([1.0, 0.7, 0.0]),
+              cos_anneal_ratio=rnd.choice([0.0, 0.3, 1.0]))
+    knobs = dict(tile_sb=rnd.choice([0, 1, 2, 4, 8, 16, 32]), tile_chunk=rnd.choice([0, 0, 1, 3, 8, 64]),
+                 grad_copies=rnd.choice([1, 1, 2, 3]), exact_f32=rnd.random() < 0.25, wgrad_f32=rnd.random() < 0.15)
+    near, far = rnd.choice([(0.1, 4.0), (0.3, 3.2), (1.0, 2.0)])
+    return P, n_view, R, Hh, Ww, S, rc, knobs, near, far, rnd.random() < 0.5
+
+
+@pytest.mark.parametrize("seed", range(48))  # (96 seeds were run once at the end of round 3: all pass)
+def test_random_configuration_matches_oracle(mods, seed):
+    P, n_view, R, Hh, Ww, S, rck, knobs, near, far, jittered = _case(seed)
+    g = torch.Generator().manual_seed(seed)
+    cache = torch.randn(P, 6, 32, R, R, generator=g) * 0.5
+    sw = O.init_mlp_weights([32, 64, 64, 1], g)
+    fw = O.init_mlp_weights([96, 64, 64, 3], g)
+    ro, rd, c2w, cd = O.make_cameras(P * n_view, Hh, Ww)
+    n_rays = P * n_view * Hh * Ww
+    ts, te = O.uniform_intervals(n_rays, S, near, far)
+    if jittered:  # stratified edges: interval lengths differ per sample and per ray
+        edges = torch.cat([ts[:, :1], te], dim=1)
+        w = (far - near) / S
+        edges[:, 1:-1] += (torch.rand(n_rays, S - 1, generator=g) - 0.5) * 0.9 * w
+        ts, te = edges[:, :-1].contiguous(), edges[:, 1:].contiguous()
+    bg = torch.rand(3, generator=g)
+    proj = {n: torch.randn(P * n_view, Hh, Ww, c, generator=g) for n, c in KEYS}
+    out, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, dict(rck, **knobs))
+    o32, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    o64, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    case = f"test_gpu_fuzz[{seed}] P{P} v{n_view} R{R} {Hh}x{Ww} S{S} {rck} {knobs}"
+    check_outputs(case, out, o32, o64, [k for k, _ in KEYS])
+    assert abs(l_hip - l64) <= max(4 * abs(l32 - l64), 1e-5 * abs(l64), 1e-6), (case, l_hip, l32, l64)
+    nz = [i for i, t in enumerate(g64) if float(t.abs().max()) > 0]  # (rgb_grad_shrink = 0, S = 1 ...: skip all-zero grads)
+    names = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]
+    check_grads(case, [g_hip[i] for i in nz], [g32[i] for i in nz], [g64[i] for i in nz], names=[names[i] for i in nz],
+                elem=False, noise32=0.5)
+    for i in set(range(7)) - set(nz):
+        assert float(g_hip[i].abs().max()) == 0.0, (case, names[i])
