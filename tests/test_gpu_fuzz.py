@@ -58,3 +58,53 @@ def test_random_configuration_matches_oracle(mods, seed):
                 elem=False, noise32=0.5)
     for i in set(range(7)) - set(nz):
         assert float(g_hip[i].abs().max()) == 0.0, (case, names[i])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_point_query_matches_oracle(seed):
+    """geometry.forward on random point clouds (inside and outside the box), random prompt / view / plane sizes:
+    outputs, d/d planes, d/d weights and d/d points (second order through sdf_grad / normal) against the oracle."""
+    import triplaneturbo_amd as tt
+    rnd = random.Random(5000 + seed)
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(100 + seed)
+    g = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
+    g.exact_f32 = rnd.random() < 0.25
+    gen = torch.Generator().manual_seed(200 + seed)
+    P, vpp = rnd.choice([1, 2, 3]), rnd.choice([1, 2, 4])
+    N, R = rnd.choice([1, 2, 31, 32, 33, 64, 100, 257]), rnd.choice([8, 12, 32, 36, 48])
+    output_normal = rnd.random() < 0.7
+    spread = rnd.choice([1.8, 2.2, 3.0])
+    cache = torch.randn(P, 6, 32, R, R, generator=gen) * 0.5
+    pts = torch.rand(P * vpp, N, 3, generator=gen) * spread - spread / 2
+    sw = [w.detach().cpu() for w in g.sdf_network.weights()]
+    fw = [w.detach().cpu() for w in g.feature_network.weights()]
+    keys = ("sdf", "features") + (("sdf_grad", "normal") if output_normal else ())
+    proj = {k: torch.randn(P * vpp * N, 1 if k == "sdf" else 3, generator=gen) for k in keys}
+
+    def oracle(dt):
+        x = pts.to(dt).requires_grad_(True)
+        c = cache.to(dt).requires_grad_(True)
+        ws = [w.to(dt).requires_grad_(True) for w in sw + fw]
+        o = O.geometry_forward(x, c.repeat_interleave(vpp, 0), ws[:3], ws[3:], output_normal=output_normal,
+                               create_graph=True)
+        loss = sum((o[k] * proj[k].to(dt)).sum() for k in keys)
+        return o, torch.autograd.grad(loss, [x, c] + ws)
+
+    o32, g32 = oracle(torch.float32)
+    o64, g64 = oracle(torch.float64)
+    x = pts.to(dev).requires_grad_(True)
+    c = cache.to(dev).requires_grad_(True)
+    out = g(x, c, output_normal=output_normal)
+    case = f"test_gpu_fuzz points[{seed}] P{P} vpp{vpp} N{N} R{R} normal={output_normal} exact={g.exact_f32}"
+    for k in keys:
+        e_hip = (out[k].detach().cpu().double().reshape(o64[k].shape) - o64[k].detach()).abs().max().item()
+        e_cpu = (o32[k].detach().double() - o64[k].detach()).abs().max().item()
+        assert e_hip <= max(4 * e_cpu, 2e-5), (case, k, e_hip, e_cpu)
+    loss = sum((out[k].reshape(-1, proj[k].shape[1]) * proj[k].to(dev)).sum() for k in keys)
+    params = [x, c] + list(g.sdf_network.weights()) + list(g.feature_network.weights())
+    g_hip = torch.autograd.grad(loss, params)
+    names = ["points", "planes", "w1", "w2", "w3", "v1", "v2", "v3"]
+    nz = [i for i, t in enumerate(g64) if float(t.abs().max()) > 0]
+    check_grads(case, [g_hip[i].cpu().reshape(g64[i].shape) for i in nz], [g32[i] for i in nz], [g64[i] for i in nz],
+                names=[names[i] for i in nz], elem=False, noise32=0.5)
