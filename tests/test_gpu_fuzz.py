@@ -108,3 +108,32 @@ def test_random_point_query_matches_oracle(seed):
     nz = [i for i, t in enumerate(g64) if float(t.abs().max()) > 0]
     check_grads(case, [g_hip[i].cpu().reshape(g64[i].shape) for i in nz], [g32[i] for i in nz], [g64[i] for i in nz],
                 names=[names[i] for i in nz], elem=False, noise32=0.5)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_eval_render_equals_training_forward(seed):
+    """The fused eval kernel with both thresholds at 0 against the training forward kernels on random configurations
+    (two different work decompositions of the same arithmetic: ray tiles walked front to back vs (ray block, chunk) items)."""
+    from triplaneturbo_amd import ops
+    rnd = random.Random(9000 + seed)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(300 + seed)
+    P, n_view = rnd.choice([1, 2, 3]), rnd.choice([1, 2, 4])
+    R = rnd.choice([8, 20, 32, 48, 64])
+    Hh, Ww, S = rnd.randint(1, 20), rnd.randint(1, 20), rnd.choice([1, 2, 31, 32, 33, 64, 100, 128])
+    cache = torch.randn(P, 6, 32, R, R, generator=g) * 0.5
+    sw = O.init_mlp_weights([32, 64, 64, 1], g)
+    fw = O.init_mlp_weights([96, 64, 64, 3], g)
+    ro, rd, _, _ = O.make_cameras(P * n_view, Hh, Ww)
+    ts, te = O.uniform_intervals(P * n_view * Hh * Ww, S, 0.1, 4.0)
+    packed = ops.planes_pack(cache.to(dev))
+    args = (packed, [w.to(dev) for w in sw], [w.to(dev) for w in fw], ro.reshape(-1, 3).to(dev),
+            rd.reshape(-1, 3).to(dev), ts.to(dev), te.to(dev), Hh * Ww)
+    rc = ops.RenderConfig(inv_std=rnd.choice([10.0, 100.0]), exact_f32=rnd.random() < 0.25,
+                          cos_anneal_ratio=rnd.choice([0.0, 1.0]), tile_sb=rnd.choice([0, 1, 4]))
+    image_w = rnd.choice([Ww, 0])  # 0: the kernels see no image (linear 32-ray strips)
+    want = ops.render_forward_raw(*args, rc, image_w=image_w)
+    got = ops.render_eval_raw(*args, rc, image_w=image_w)
+    for k in ("opacity", "depth", "rgb_fg", "z_variance", "normal_acc"):
+        torch.testing.assert_close(got[k], want[k], rtol=2e-5, atol=2e-5 if k == "z_variance" else 2e-6,
+                                   msg=lambda m, k=k: f"{k} seed {seed} P{P} v{n_view} R{R} {Hh}x{Ww} S{S}: {m}")
