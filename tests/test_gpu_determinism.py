@@ -157,3 +157,31 @@ def test_gradient_wrt_query_points_is_bitwise_reproducible():
             assert torch.isfinite(ref).all()
         else:
             assert torch.equal(ref, gx), (it, (ref != gx).any(-1).nonzero().flatten()[:8].tolist())
+
+
+def test_ray_march_forward_and_backward_are_bitwise_reproducible():
+    """tt_march_fwd / tt_march_bwd have no atomics (one wave per ray, DPP scans): every output -- including the
+    (n_rays*S, 4) upstream workspace the geometry backward consumes -- must be bit-identical over repeated launches."""
+    from triplaneturbo_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(41)
+    n_rays, S = 3001, 193
+    rd = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1).to(dev)
+    ts, te = [t.to(dev) for t in O.uniform_intervals(n_rays, S, 0.1, 4.0)]
+    sdf = (torch.randn(n_rays * S, 1, generator=g) * 0.05).to(dev)
+    sdf_grad = torch.randn(n_rays * S, 3, generator=g).to(dev)
+    feat = torch.randn(n_rays * S, 3, generator=g).to(dev)
+    ups = dict(g_opacity=torch.randn(n_rays, 1, generator=g).to(dev), g_depth=torch.randn(n_rays, 1, generator=g).to(dev),
+               g_rgb_fg=torch.randn(n_rays, 3, generator=g).to(dev), g_z_variance=torch.randn(n_rays, 1, generator=g).to(dev),
+               g_normal_acc=torch.randn(n_rays, 3, generator=g).to(dev),
+               g_sdf_grad=(torch.randn(n_rays * S, 3, generator=g) * 1e-3).to(dev))
+    rc = ops.RenderConfig(inv_std=60.0, cos_anneal_ratio=0.5)
+    fwd0 = ops.march_forward_raw(rd, ts, te, sdf, sdf_grad, feat, rc)
+    ws0 = ops.march_backward_raw(rd, ts, te, fwd0, sdf, sdf_grad, feat, rc, **ups)
+    assert torch.isfinite(ws0).all()
+    for it in range(12):
+        fwd = ops.march_forward_raw(rd, ts, te, sdf, sdf_grad, feat, rc)
+        for k in fwd0:
+            assert torch.equal(fwd[k], fwd0[k]), (it, k)
+        ws = ops.march_backward_raw(rd, ts, te, fwd, sdf, sdf_grad, feat, rc, **ups)
+        assert torch.equal(ws, ws0), it
