@@ -82,6 +82,15 @@ __device__ __forceinline__ void stage_image16(float* dst_f, const float* __restr
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
+// Wave priority during the MFMA chain of a product.  A translation unit whose kernels run TWO waves per SIMD (the forward
+// kernels) defines TT_MV16_PRIO 1 before including this header: the wave that is in its matrix phase is issued first, so
+// the matrix pipe stays fed while the other wave of the SIMD does its VALU / memory phase (forward 1.79 -> 1.68 ms).  With
+// one wave per SIMD (backward kernels) there is nobody to be prioritised over and the instruction only pins hipcc's
+// schedule (geometry backward 2.85 -> 2.97 ms): default 0 = not emitted.
+#ifndef TT_MV16_PRIO
+#define TT_MV16_PRIO 0
+#endif
+
 // y[NOUT] = M[NOUT][NIN] x[NIN], M given as an image; x, y in the LIDX register layout.
 // SCALED: every sample (= MFMA column = this lane and its partner lane ^ 32) is first normalised by the power of two
 // that brings its largest |x| into [2^14, 2^15) and the result is scaled back -- exact, and it makes the product
@@ -108,6 +117,7 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
 #pragma unroll
     for (int m = 0; m < MT; ++m)
         acc[m] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (TT_MV16_PRIO) __builtin_amdgcn_s_setprio(TT_MV16_PRIO);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         // split the 8 activations of this k-step
@@ -140,6 +150,7 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
     }
+    if (TT_MV16_PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
