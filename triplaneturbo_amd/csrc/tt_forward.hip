@@ -1,5 +1,7 @@
 // tt_forward.hip -- plane pack/unpack, per-point decode (tt_query_points) and the fused forward render.
-#define TT_MV16_PRIO 1  // two waves per SIMD in this unit: see tt_mfma16.h
+#ifndef TT_MV16_FENCE
+#define TT_MV16_FENCE 1  // scheduling fence in front of every product's MFMA loop: see tt_mfma16.h
+#endif
 #include "tt_device.h"
 #include "tt_mfma16.h"
 #include "tt_alpha.h"

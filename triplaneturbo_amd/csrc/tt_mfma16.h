@@ -82,13 +82,14 @@ __device__ __forceinline__ void stage_image16(float* dst_f, const float* __restr
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
-// Wave priority during the MFMA chain of a product.  A translation unit whose kernels run TWO waves per SIMD (the forward
-// kernels) defines TT_MV16_PRIO 1 before including this header: the wave that is in its matrix phase is issued first, so
-// the matrix pipe stays fed while the other wave of the SIMD does its VALU / memory phase (forward 1.79 -> 1.68 ms).  With
-// one wave per SIMD (backward kernels) there is nobody to be prioritised over and the instruction only pins hipcc's
-// schedule (geometry backward 2.85 -> 2.97 ms): default 0 = not emitted.
-#ifndef TT_MV16_PRIO
-#define TT_MV16_PRIO 0
+// Compiler scheduling fence in front of the split + MFMA loop of a product (after the per-sample scale search): hipcc may
+// not mix the tail of the previous product / the scale search into the loop, nor hoist the loop's LDS reads above it.
+// Measured per translation unit: the forward kernels gain 6-7 % (k_decode_rays 1.80 -> 1.68 ms, the fused eval kernel
+// 2.38 -> 1.93 ms), so tt_forward.hip defines TT_MV16_FENCE 1 before including this header; the backward kernels do not
+// (profiles/experiments/README.md).  __builtin_amdgcn_sched_barrier emits no instruction.  (Found through s_setprio around
+// the loop, which helps by the same amount with priority 0: it is the fence, not the wave priority, that matters.)
+#ifndef TT_MV16_FENCE
+#define TT_MV16_FENCE 0
 #endif
 
 // y[NOUT] = M[NOUT][NIN] x[NIN], M given as an image; x, y in the LIDX register layout.
@@ -117,7 +118,7 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
 #pragma unroll
     for (int m = 0; m < MT; ++m)
         acc[m] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (TT_MV16_PRIO) __builtin_amdgcn_s_setprio(TT_MV16_PRIO);
+    if (TT_MV16_FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         // split the 8 activations of this k-step
@@ -150,7 +151,6 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
     }
-    if (TT_MV16_PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
