@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         for (int r = 0; r < 32; ++r) kb1[r] = k1[r] > 0.f ? kb1[r] : 0.f;
         TT_PHASE(6);
         if (do_wgrad) {
+            // (compiler scheduling fence in front of the outer products: 2.88 -> 2.85 ms; the same fence in front of the
+            // dV2 products, or both, gains nothing -- profiles/experiments/README.md)
+            __builtin_amdgcn_sched_barrier(0);
             // ---- dV1 += k1bar e^T  (e parked in Ys rows 0..95; k1bar through the 32-row window, half by half) ----
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
