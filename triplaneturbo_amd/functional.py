@@ -90,7 +90,7 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
     eval_termination_eps > 0 (opt-in) they run on the fused decode + march kernel (tt_render_eval), which stops rays whose
     transmittance fell below eps and skips texture decodes of weights below eps / S (per-ray error of opacity / rgb
     < 2 eps).  With the default 0 nothing can be skipped, and the training forward kernels -- (ray block, depth chunk)
-    work items on a dynamic queue instead of one sequential walk per ray tile -- are faster (2.06 vs 2.38 ms at
+    work items on a dynamic queue instead of one sequential walk per ray tile -- are at least as fast (1.88 vs 1.91 ms at
     256 x 256 x 128, tools/time_eval_paths.py; the per-sample buffers are temporaries of the call)."""
     B, Hh, Ww, _ = rays_o.shape
     n_rays = B * Hh * Ww
