@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 12
+#define TT_ABI_VERSION 13
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -147,6 +147,9 @@ typedef struct {
 
 const char* tt_strerror(int status);
 int tt_abi_version(void);
+/* sha256 (hex) of the sources and build flags the library was built from ("unknown" for a hand-made build): the host
+ * side rebuilds when it differs from the tree (triplaneturbo_amd/_lib.py), whatever the file times say. */
+const char* tt_source_hash(void);
 /* Test hook: leaves the work-queue counters of `stream` dirty, as a faulted kernel would; the next launch on that
  * stream must be unaffected (the counters are zeroed on the stream in front of every launch). */
 int tt_debug_poison_queue(void* stream);

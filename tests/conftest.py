@@ -22,7 +22,7 @@ def golden_dir():
 @pytest.fixture(scope="session", autouse=True)
 def _built_library():
     """Explicit build step (NOT a fallback): the HIP library is compiled in-tree with hipcc before any test uses it;
-    a no-op when triplaneturbo_amd/libtt_hip.so is newer than its sources."""
+    a no-op when the source hash embedded in triplaneturbo_amd/libtt_hip.so matches the tree."""
     from triplaneturbo_amd import _lib
     if os.environ.get("TT_LIB_VARIANT"):  # dev only: run the suite against an experiment build (tools/build_variants.py)
         _lib.use_variant(os.environ["TT_LIB_VARIANT"])

@@ -21,3 +21,19 @@ def test_eikonal_loss_matches_torch(n):
     gg, = torch.autograd.grad(got, [xg])
     torch.testing.assert_close(got.cpu().double(), want.detach(), rtol=2e-6, atol=1e-7)
     torch.testing.assert_close(gg.cpu().double(), gw, rtol=2e-5, atol=1e-9)
+
+
+def test_eikonal_loss_is_bit_reproducible_and_survives_huge_values():
+    """The forward combines its per-block partial sums in a fixed-point integer accumulator: repeated launches are
+    BIT-identical whatever order the blocks arrive in; a diverged field (block share of the mean >= 1024) takes the
+    float fallback and is still right."""
+    from triplaneturbo_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(300007, 3, generator=g) * 1.1).cuda()
+    ref = ops.eikonal_loss(x).item()
+    for _ in range(20):
+        assert ops.eikonal_loss(x).item() == ref
+    big = (torch.randn(70001, 3, generator=g) * 4.0e3).cuda()
+    want = ((torch.linalg.norm(big.double(), ord=2, dim=-1) - 1.0) ** 2).mean().item()
+    assert abs(ops.eikonal_loss(big).item() - want) <= 2e-6 * want
+    assert torch.isnan(ops.eikonal_loss(torch.full((5, 3), float("nan")).cuda()))

@@ -84,6 +84,16 @@ def test_C_schedule_matches_reference_semantics():
     assert registry.C([1.0, 0.0, 100], 0, 50) == 0.5  # 3-element form gets a 0 start step
     assert registry.C([0, 0.0, 1.0, 10, 3.0, 20], 0, 15) == 2.0  # piecewise form
     assert registry.C([0, 1.0, 0.0, 2.0], 1, 999) == 0.5  # float end_step => epochs
+    # three chained ramps (values of threestudio/utils/misc.py:69-104 on the same list), incl. the hand-over steps
+    spec = [0, 0.0, 1.0, 10, 3.0, 20, 2.0, 40]
+    want = {0: 0.0, 5: 0.5, 10: 1.0, 15: 2.0, 20: 3.0, 30: 2.5, 40: 2.0, 100: 2.0}
+    for step, v in want.items():
+        assert registry.C(spec, 0, step) == v, step
+    assert abs(registry.C([10, 0.1, 1.0, 110], 0, 60, "exp") - 0.1 ** 0.5) < 1e-15
+    with pytest.raises(ValueError):
+        registry.C([0, 1.0, 2.0, 10], 0, 5, "cubic")
+    with pytest.raises(AssertionError):
+        registry.C([0, 1.0, 2.0, 10, 5.0], 0, 5)
 
 
 def test_sampler_has_no_cpu_path():
@@ -164,8 +174,39 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == 12
+    assert lib.tt_abi_version() == _lib._expected_abi() == 13
     assert b"bad argument" in lib.tt_strerror(-1)
+    # the binary carries the hash of the sources + flags it was built from, and that is what "up to date" means
+    lib.tt_source_hash.restype = ctypes.c_char_p
+    assert lib.tt_source_hash().decode() == _lib.source_hash() == _lib.embedded_hash(path)
+    assert not _lib.needs_build(path)
+
+
+def test_stale_library_is_rebuilt_whatever_its_mtime(tmp_path, monkeypatch):
+    """needs_build compares the embedded source hash, not file times: a library whose sources changed is stale even when
+    it is NEWER than every source (a pushed tree, a checkout), and a library without a hash is always stale."""
+    path = _lib.build()
+    fake = tmp_path / "libtt_fake.so"
+    blob = open(path, "rb").read()
+    fake.write_bytes(blob)
+    assert not _lib.needs_build(str(fake))
+    good = _lib.embedded_hash(path).encode()
+    fake.write_bytes(blob.replace(good, b"0" * 64))  # same file, other sources
+    os.utime(fake, (2e9, 2e9))                       # ... and far newer than the tree
+    assert _lib.needs_build(str(fake))
+    fake.write_bytes(b"no hash in here")
+    assert _lib.needs_build(str(fake))
+    # a change of the build flags is a change of the binary too
+    assert _lib.source_hash(defines=["-DX"]) != _lib.source_hash()
+    assert _lib.source_hash(tuning=True) != _lib.source_hash()
+
+
+def test_load_refuses_an_abi_mismatch(monkeypatch):
+    _lib.load()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_expected_abi", lambda: 999)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.load()
 
 
 def test_ctypes_struct_layout_matches_header(tmp_path):

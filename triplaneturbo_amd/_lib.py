@@ -6,8 +6,11 @@ any op fails loudly.  ``build()`` cross-compiles for gfx950 with hipcc (works wi
 from __future__ import annotations
 
 import ctypes
+import hashlib
 import os
+import re
 import subprocess
+import tempfile
 from typing import List, Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -37,7 +40,7 @@ SYMBOLS = [
     "tt_march_fwd", "tt_march_bwd", "tt_sample_uniform", "tt_sample_importance",
     "tt_points_bwd_geo", "tt_points_bwd_tex", "tt_points_bwd_x", "tt_hashgrid_n_params", "tt_hashgrid_fwd", "tt_hashgrid_bwd",
     "tt_debug_poison_queue", "tt_patch_composite_fwd", "tt_patch_composite_bwd", "tt_render_eval",
-    "tt_composite_fwd", "tt_composite_bwd", "tt_eikonal_fwd", "tt_eikonal_bwd",
+    "tt_composite_fwd", "tt_composite_bwd", "tt_eikonal_fwd", "tt_eikonal_bwd", "tt_source_hash",
 ]
 
 
@@ -45,33 +48,103 @@ def _sources() -> List[str]:
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
-def needs_build(path: str = LIB_PATH) -> bool:
+def _expected_abi() -> int:
+    m = re.search(r"#define\s+TT_ABI_VERSION\s+(\d+)", open(os.path.join(INCLUDE, "tt_abi.h")).read())
+    if not m:
+        raise RuntimeError("include/tt_abi.h has no TT_ABI_VERSION")
+    return int(m.group(1))
+
+
+def _deps() -> List[str]:
+    deps = _sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    deps.append(os.path.join(INCLUDE, "tt_abi.h"))
+    return deps
+
+
+def source_hash(tuning: bool = False, defines: Optional[List[str]] = None, source_flags: Optional[dict] = None) -> str:
+    """sha256 over every source / header of the library AND the flags it is built with.  build() embeds it in the
+    binary (`tt_source_hash()`, marker string TT_SOURCE_HASH=...); needs_build() compares the embedded value with the
+    tree, so a .so that travelled with equal or newer mtimes than its sources (a pushed tree, a checkout) is never
+    silently reused for different sources."""
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode() + b"\0")
+        h.update(open(d, "rb").read())
+        h.update(b"\0")
+    flags = dict(SOURCE_FLAGS if source_flags is None else source_flags)
+    h.update(repr((HIPCC_FLAGS, sorted(flags.items()), bool(tuning), list(defines or []))).encode())
+    return h.hexdigest()
+
+
+_HASH_RE = re.compile(rb"TT_SOURCE_HASH=([0-9a-f]{64})")
+
+
+def embedded_hash(path: str) -> Optional[str]:
+    """The source hash a built library carries (read from the file, no dlopen), or None."""
+    try:
+        m = _HASH_RE.search(open(path, "rb").read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
+def needs_build(path: str = LIB_PATH, tuning: bool = False, defines: Optional[List[str]] = None,
+                source_flags: Optional[dict] = None) -> bool:
     if not os.path.exists(path):
         return True
-    t = os.path.getmtime(path)
-    deps = _sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps.append(os.path.join(INCLUDE, "tt_abi.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return embedded_hash(path) != source_hash(tuning, defines, source_flags)
+
+
+_FLAG_OK: dict = {}
+
+
+def _flag_supported(hipcc: str, pair: List[str]) -> bool:
+    """Performance-only `-mllvm` options are hidden LLVM flags: probe each once on an empty translation unit, so that a
+    hipcc without one of them builds the library without it (with a warning) instead of failing the whole build."""
+    key = " ".join(pair)
+    if key not in _FLAG_OK:
+        with tempfile.TemporaryDirectory(prefix="tt_flag_") as d:
+            src = os.path.join(d, "e.hip")
+            open(src, "w").write("__global__ void k() {}\n")
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-c", src, "-o", os.path.join(d, "e.o")] + pair,
+                               capture_output=True, text=True)
+        _FLAG_OK[key] = r.returncode == 0
+        if r.returncode != 0:
+            print(f"triplaneturbo_amd: hipcc rejects '{key}' (performance-only flag): building without it")
+    return _FLAG_OK[key]
+
+
+def _usable_flags(hipcc: str, flags: List[str]) -> List[str]:
+    out, i = [], 0
+    while i < len(flags):
+        pair = flags[i:i + 2] if flags[i] == "-mllvm" else flags[i:i + 1]
+        if flags[i] != "-mllvm" or _flag_supported(hipcc, pair):
+            out += pair
+        i += len(pair)
+    return out
 
 
 def build(force: bool = False, verbose: bool = False, tuning: bool = False, variant: Optional[str] = None,
           defines: Optional[List[str]] = None, source_flags: Optional[dict] = None) -> str:
     """hipcc --offload-arch=gfx950 ... -shared -> triplaneturbo_amd/libtt_hip.so (in-tree).  One hipcc process per
     translation unit, in parallel, then a link.  tuning=True builds the dev variant libtt_hip_tuning.so instead;
-    variant="x" + defines=["-DFOO"] builds an experiment library libtt_hip_x.so (dev A/B runs, tools/ab.sh)."""
+    variant="x" + defines=["-DFOO"] builds an experiment library libtt_hip_x.so (dev A/B runs, tools/ab.sh).
+    Up to date = the source hash embedded in the library equals the hash of the tree (source_hash), not mtimes."""
     out = TUNING_LIB_PATH if tuning else LIB_PATH
     if variant:
         out = os.path.join(_HERE, f"libtt_hip_{variant}.so")
-    if not force and not needs_build(out):
+    if not force and not needs_build(out, tuning, defines, source_flags):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(_HERE, "build", variant or ("tuning" if tuning else "release"))
     os.makedirs(objdir, exist_ok=True)
+    digest = source_hash(tuning, defines, source_flags)
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DTT_TUNING"] if tuning else []) + list(defines or [])
+    flags.append(f'-DTT_SOURCE_HASH_STR="{digest}"')
     procs = []
     for s in _sources():
         obj = os.path.join(objdir, os.path.basename(s) + ".o")
-        per_unit = (SOURCE_FLAGS if source_flags is None else source_flags).get(os.path.basename(s), [])
+        per_unit = _usable_flags(hipcc, (SOURCE_FLAGS if source_flags is None else source_flags).get(os.path.basename(s), []))
         cmd = [hipcc] + flags + per_unit + ["-I", INCLUDE, "-I", CSRC, "-x", "hip", "-c", s, "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -87,6 +160,8 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, vari
     if r.returncode != 0:
         raise RuntimeError(f"hipcc link failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
     os.replace(out + ".tmp", out)
+    if embedded_hash(out) != digest:
+        raise RuntimeError(f"{out} does not carry the source hash it was built with")
     return out
 
 
@@ -160,6 +235,12 @@ def load() -> ctypes.CDLL:
     lib.tt_strerror.restype = ctypes.c_char_p
     lib.tt_strerror.argtypes = [ctypes.c_int]
     lib.tt_abi_version.restype = ctypes.c_int
+    lib.tt_source_hash.restype = ctypes.c_char_p
+    lib.tt_source_hash.argtypes = []
+    if lib.tt_abi_version() != _expected_abi():
+        # argument lists moved between ABI versions: calling a stale library would shift pointer arguments
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.tt_abi_version()}, include/tt_abi.h declares "
+                           f"{_expected_abi()}: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     lib.tt_planes_pack.argtypes = [_P, _P, _I32, _I32, _I32, _P]
     lib.tt_planes_unpack_grad.argtypes = [_P, _P, _I32, _I32, _I32, _I32, _P]
     lib.tt_query_points.argtypes = [_P, ctypes.POINTER(MlpWeights), _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F,
@@ -196,7 +277,8 @@ def load() -> ctypes.CDLL:
         if name in SYMBOLS:
             getattr(lib, name).argtypes = argtypes
     for name in SYMBOLS[2:]:
-        getattr(lib, name).restype = ctypes.c_int
+        if name != "tt_source_hash":
+            getattr(lib, name).restype = ctypes.c_int
     lib.tt_hashgrid_n_params.restype = ctypes.c_int64
     _lib = lib
     return lib

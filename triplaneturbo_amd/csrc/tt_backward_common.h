@@ -114,11 +114,9 @@ __device__ __forceinline__ float wg16_scale(float bound) {
     E = E < 16 ? 16 : (E > 240 ? 240 : E);
     return __builtin_bit_cast(float, (unsigned)(268 - E) << 23);
 }
-__device__ __forceinline__ unsigned wg16_pack(float x) {  // (hi | lo << 16), both round-toward-zero: hi + lo ~ x
-    // (hi by masking the fp32 significand to 11 bits instead of the convert / convert-back pair: same speed, measured)
-    const unsigned p = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, 0.f));
-    const float hf = (float)__builtin_bit_cast(h2_t, p).x;
-    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, x - hf));
+__device__ __forceinline__ unsigned wg16_pack(float x) {  // (hi | lo << 16), both round-to-nearest-even: hi + lo ~ x
+    const float hf = (float)cvt_pk16(x, 0.f).x;
+    return cvt_pk16u(x, x - hf);
 }
 template <int N>
 __device__ __forceinline__ void stage_rows16(float* S, const float (&v)[N / 2], int j, int hi, float sc) {
@@ -520,9 +518,8 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float x0 = bs[ks][2 * j] * bsc, x1 = bs[ks][2 * j + 1] * bsc;
-                    const h2_t ph = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-                    const h2_t pq =
-                        __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0 - (float)ph.x, x1 - (float)ph.y));
+                    const h2_t ph = cvt_pk16(x0, x1);
+                    const h2_t pq = cvt_pk16(x0 - (float)ph.x, x1 - (float)ph.y);
                     bh[ks][2 * j] = ph.x;
                     bh[ks][2 * j + 1] = ph.y;
                     bl[ks][2 * j] = pq.x;

@@ -351,22 +351,44 @@ extern "C" int tt_composite_bwd(const float* opacity, const float* depth, const 
 //   loss = mean((||sdf_grad||_2 - 1)^2)      (multiprompt_dual_renderer_multistep_generator.py:696-699)
 // The reference evaluates it with five element-wise / reduction torch kernels over the (N,3) per-sample tensor and
 // as many again in the backward (N = 8.4 M samples at the headline size: ~0.3 ms of pure HBM traffic); here it is one
-// pass each way.  Forward: per-block partial sums in double, one atomic per block.  Backward:
+// pass each way.  Forward: per-block partial sums in double, one (integer, order-independent) atomic per block.  Backward:
 //   d loss / d g = g_loss * 2 (||g|| - 1) / (N ||g||) * g     (0 where ||g|| = 0, like torch's norm backward)
 // =====================================================================================================
+// Run-to-run DETERMINISTIC: a block's contribution to the mean (a double) is added to a 64-bit FIXED-POINT accumulator
+// (resolution 2^-44: integer addition is associative, so the order in which the blocks arrive does not matter; total
+// rounding <= blocks x 2^-45 = 1.5e-11 absolute), and the last block to arrive converts the sum to the fp32 loss.  A block
+// whose mean contribution is >= 1024 (a diverged field: the fixed-point range ends at 2^19) goes to a plain float atomic
+// instead -- correct, just not bit-reproducible.  acc: 4 zeroed ints of the launch's scratch slot (tt_host.h):
+// [0..1] the accumulator, [2] the overflow float, [3] the arrival counter.
+#define TT_EIK_FRAC 0x1p44
 __global__ __launch_bounds__(256) void k_eikonal_fwd(const float* __restrict__ g, long long n, double inv_n,
-                                                     float* __restrict__ out) {
-    double acc = 0.0;
+                                                     int* __restrict__ acc, float* __restrict__ out) {
+    double sum = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float x = g[i * 3 + 0], y = g[i * 3 + 1], z = g[i * 3 + 2];
         const float d = sqrtf(x * x + y * y + z * z) - 1.f;
-        acc += (double)(d * d);
+        sum += (double)(d * d);
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     __shared__ double part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, (float)((part[0] + part[1] + part[2] + part[3]) * inv_n));
+    if (threadIdx.x == 0) {
+        const double c = ((part[0] + part[1]) + (part[2] + part[3])) * inv_n;  // this block's share of the mean (>= 0)
+        unsigned long long* fix = reinterpret_cast<unsigned long long*>(acc);
+        float* ovf = reinterpret_cast<float*>(acc + 2);
+        if (c < 1024.0)
+            atomicAdd(fix, (unsigned long long)(c * TT_EIK_FRAC + 0.5));
+        else
+            atomicAdd(ovf, (float)c);  // also NaN: !(NaN < 1024)
+        __threadfence();
+        if (atomicAdd(acc + 3, 1) == (int)gridDim.x - 1) {
+            __threadfence();
+            const unsigned long long total = __hip_atomic_load(fix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float extra = __hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[0] = (float)((double)total * (1.0 / TT_EIK_FRAC) + (double)extra);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_eikonal_bwd(const float* __restrict__ g, const float* __restrict__ g_loss,
@@ -385,10 +407,12 @@ __global__ __launch_bounds__(256) void k_eikonal_bwd(const float* __restrict__ g
 extern "C" int tt_eikonal_fwd(const float* sdf_grad, int64_t n, float* loss, void* stream) {
     if (!sdf_grad || !loss || n <= 0) return TT_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return TT_ERR_LAUNCH;
     long long blocks = (n + 255) / 256;
     if (blocks > 512) blocks = 512;  // one same-address atomic per workgroup: they serialise at ~11 ns each
-    hipLaunchKernelGGL(k_eikonal_fwd, dim3((unsigned)blocks), dim3(256), 0, s, sdf_grad, (long long)n, 1.0 / (double)n, loss);
+    int* slot = tt_queue_counters(s);  // zeroed on the stream in front of this launch
+    if (!slot) return TT_ERR_DEVICE;
+    hipLaunchKernelGGL(k_eikonal_fwd, dim3((unsigned)blocks), dim3(256), 0, s, sdf_grad, (long long)n, 1.0 / (double)n,
+                       slot + TT_SLOT_EIKONAL, loss);
     return tt_check_launch();
 }
 

@@ -1,6 +1,7 @@
 // tt_host.cpp -- status strings, launch checking, device queries, the work-queue counter scratch
 #include "tt_host.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <mutex>
@@ -17,6 +18,14 @@ extern "C" const char* tt_strerror(int status) {
 }
 
 extern "C" int tt_abi_version(void) { return TT_ABI_VERSION; }
+
+// sha256 of the sources + build flags this binary was made from (_lib.source_hash; "unknown" for a hand-made build).
+// The marker prefix lets _lib.needs_build read it from the file without loading the library.
+#ifndef TT_SOURCE_HASH_STR
+#define TT_SOURCE_HASH_STR "unknown"
+#endif
+static const char k_source_hash[] = "TT_SOURCE_HASH=" TT_SOURCE_HASH_STR;
+extern "C" const char* tt_source_hash(void) { return k_source_hash + 15; }
 
 int tt_check_launch() { return hipGetLastError() == hipSuccess ? TT_OK : TT_ERR_LAUNCH; }
 
@@ -50,6 +59,7 @@ struct DeviceScratch {
     int n_streams = 0;
     int evict = 0;                   // next stream entry to recycle once the table is full
     unsigned n_graph = 0;
+    bool evict_warned = false;
 };
 DeviceScratch g_scratch[kMaxDevices];
 std::mutex g_scratch_mu;
@@ -74,12 +84,22 @@ int* tt_queue_counters(hipStream_t stream) {
             d.base = static_cast<int*>(ptr);
         }
         if (cap != hipStreamCaptureStatusNone) {
+            if (d.n_graph == kGraphSlots)  // said ONCE: from here on captured launches reuse slots (limits: INTEGRATION.md 3)
+                fprintf(stderr, "libtt_hip: %d launches captured on device %d; work-queue slots of captured launches are "
+                                "reused from now on -- graphs holding more than %d launches in total must not replay "
+                                "concurrently\n", kGraphSlots, dev, kGraphSlots);
             slot = d.base + (size_t)(kStreams * kRing + (d.n_graph++ % kGraphSlots)) * kSlotInts;
         } else {
             int k = 0;
             while (k < d.n_streams && d.streams[k] != stream) ++k;
             if (k == d.n_streams) {
                 if (d.n_streams == kStreams) {  // stream handles come and go: recycle the oldest entry
+                    if (!d.evict_warned) {
+                        d.evict_warned = true;
+                        fprintf(stderr, "libtt_hip: more than %d streams have launched on device %d; the oldest stream's "
+                                        "work-queue ring is recycled (safe unless more than %d streams have launches in "
+                                        "flight at once)\n", kStreams, dev, kStreams);
+                    }
                     k = d.evict;
                     d.evict = (d.evict + 1) % kStreams;
                 } else {

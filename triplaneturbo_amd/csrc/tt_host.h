@@ -31,3 +31,4 @@ int* tt_queue_counters(hipStream_t stream);
 #define TT_BOUND_PLANES 0   /* max |texel| of the three planes the kernel reads */
 #define TT_BOUND_UP0 1      /* geometry: max |d/d sdf|;            texture: max |g_rgb| */
 #define TT_BOUND_UP1 2      /* geometry: max |d/d sdf_grad| comp.; texture: max |g_features| */
+#define TT_SLOT_EIKONAL 24  /* tt_eikonal_fwd: 4 ints (8-byte aligned): fixed-point sum, overflow float, arrival counter */

@@ -29,13 +29,24 @@
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half_t;
+typedef float f2_t __attribute__((ext_vector_type(2)));
 
 #define IMG16_FLOATS(ROWS, K) ((ROWS) * ((K) + 4)) /* LDS floats one image occupies */
 
+// Two fp32 -> one dword of two fp16, ROUND-TO-NEAREST-EVEN: v_cvt_pk_f16_f32 (gfx950; one instruction per pair, like the
+// round-toward-zero v_cvt_pkrtz_f16_f32 it replaces since round 4).  With RNE |v - hi| <= 2^-11 |v| and lo = f16(v - hi)
+// is again correctly rounded, so hi + lo carries ~24 significand bits instead of the ~22 of the truncating split
+// (tools/mfma16_probe.hip measures both).  Nothing can overflow: operands are normalised below 2^15 < 65504.
+__device__ __forceinline__ h2_t cvt_pk16(float a, float b) {
+    const f2_t v = {a, b};
+    return __builtin_convertvector(v, h2_t);
+}
+__device__ __forceinline__ unsigned cvt_pk16u(float a, float b) { return __builtin_bit_cast(unsigned, cvt_pk16(a, b)); }
+
 __device__ __forceinline__ void split16(float v, half_t& hi, half_t& lo) {
-    const h2_t p = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(v, 0.f));
+    const h2_t p = cvt_pk16(v, 0.f);
     hi = p.x;
-    const h2_t q = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(v - (float)hi, 0.f));  // may be subnormal
+    const h2_t q = cvt_pk16(v - (float)hi, 0.f);  // may be subnormal
     lo = q.x;
 }
 
@@ -79,8 +90,6 @@ __device__ __forceinline__ void stage_image16(float* dst_f, const float* __restr
     }
     for (int R = threadIdx.x; R < ROWS; R += blockDim.x) dst_f[(size_t)R * (K + 4) + K] = un;
 }
-
-typedef float f2_t __attribute__((ext_vector_type(2)));
 
 // Compiler scheduling fence in front of the split + MFMA loop of a product (after the per-sample scale search): hipcc may
 // not mix the tail of the previous product / the scale search into the loop, nor hoist the loop's LDS reads above it.
@@ -127,9 +136,9 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
         for (int j = 0; j < 4; ++j) {
             const f2_t ab = {x[8 * s + 2 * j], x[8 * s + 2 * j + 1]};
             const f2_t as = SCALED ? ab * sc : ab;  // exact (power of two)
-            const h2_t p = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(as.x, as.y));
+            const h2_t p = cvt_pk16(as.x, as.y);
             const float ra = as.x - (float)p.x, rb = as.y - (float)p.y;  // exact residuals
-            const h2_t q = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+            const h2_t q = cvt_pk16(ra, rb);
             bh[2 * j] = p.x;
             bh[2 * j + 1] = p.y;
             bl[2 * j] = q.x;
@@ -173,11 +182,11 @@ __device__ __forceinline__ void split16_vec(const float (&x)[N / 2], float sc, S
     for (int t = 0; t < N / 4; ++t) {
         const f2_t ab = {x[2 * t], x[2 * t + 1]};
         const f2_t as = ab * sc;  // exact (power of two)
-        const unsigned pu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(as.x, as.y));
+        const unsigned pu = cvt_pk16u(as.x, as.y);
         const h2_t p = __builtin_bit_cast(h2_t, pu);
         const float ra = as.x - (float)p.x, rb = as.y - (float)p.y;  // exact residuals
         o.h[t] = pu;
-        o.l[t] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+        o.l[t] = cvt_pk16u(ra, rb);
     }
 }
 // mv16 on a pre-split operand: y = M x with x = (hi + lo) * un_x

@@ -12,7 +12,9 @@ from . import _lib
 from .ops import _chk, _ptr, _stream
 
 
-def grid_sample_2d(input, grid, padding_mode="zeros", align_corners=False):
+def grid_sample_2d(input, grid, padding_mode="zeros", align_corners=True):
+    # (defaults as the reference's cuda_gridsample.py:24: align_corners=True; its one call site, geometry/utils.py:23,
+    # passes False explicitly)
     assert padding_mode in ["zeros", "border"]
     return _GridSample2dForward.apply(input, grid, padding_mode, align_corners)
 
@@ -45,7 +47,7 @@ def grad2_2d(grad2_grad_input, grad2_grad_grid, grad_output, input, grid, paddin
 
 class _GridSample2dForward(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, input, grid, padding_mode="zeros", align_corners=False):
+    def forward(ctx, input, grid, padding_mode="zeros", align_corners=True):
         assert input.ndim == 4 and grid.ndim == 4 and input.shape[0] == grid.shape[0] and grid.shape[3] == 2
         output = torch.nn.functional.grid_sample(input=input, grid=grid, mode="bilinear", padding_mode=padding_mode,
                                                  align_corners=align_corners)
@@ -64,7 +66,7 @@ class _GridSample2dForward(torch.autograd.Function):
 
 class _GridSample2dBackward(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, grad_output, input, grid, padding_mode=0, align_corners=False):
+    def forward(ctx, grad_output, input, grid, padding_mode=0, align_corners=True):
         mask = (ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         grad_input, grad_grid = torch.ops.aten.grid_sampler_2d_backward(grad_output, input, grid, 0, padding_mode,
                                                                         align_corners, mask)

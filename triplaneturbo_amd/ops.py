@@ -410,13 +410,13 @@ def render_eval_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Te
     return out
 
 
-@torch.no_grad()
 def _placement(name: str) -> int:
     if name not in _lib.PLACEMENTS:
         raise ValueError(f"placement must be one of {sorted(_lib.PLACEMENTS)}, got {name!r}")
     return _lib.PLACEMENTS[name]
 
 
+@torch.no_grad()
 def sample_uniform(n_rays: int, n_samples: int, near: float, far: float, device, jitter: Optional[Tensor] = None,
                    placement: str = "tt"):
     """tt_sample_uniform: level-0 intervals (n_rays, n_samples); jitter (n_rays, n_samples+1) U[0,1) => stratified;

@@ -58,59 +58,65 @@ def parse_structured(fields: Any, cfg: Optional[Any] = None) -> Any:
     return fields(**cfg)
 
 
+def _schedule_segment(spec, global_step):
+    """The (start_step, start_value, end_value, end_step) segment of a piecewise schedule
+    [s0, v0, v1, s1, v2, s2, ...] that is active at `global_step`: segment k runs from (s_k, v_k) to (s_{k+1}, v_{k+1});
+    the last segment whose END step has been reached hands over to the next one."""
+    knots = [(spec[0], spec[1])] + [(spec[j + 1], spec[j]) for j in range(2, len(spec) - 1, 2)]  # (step, value) pairs
+    k = 0
+    while k + 2 < len(knots) and global_step >= knots[k + 1][0]:
+        k += 1
+    (s0, v0), (s1, v1) = knots[k], knots[k + 1]
+    return s0, v0, v1, s1
+
+
 def C(value: Any, epoch: int, global_step: int, interpolation: str = "linear") -> float:
-    """Scheduled scalar: number, [start_step, start_value, end_value, end_step] or the 3-/6+-element forms
-    (threestudio/utils/misc.py:69-104)."""
+    """Scheduled scalar with the semantics of threestudio's `C` (threestudio/utils/misc.py:69-104; checked against it
+    value for value in tests/test_host_logic.py): a plain number is returned as is; [v0, v1, s1] starts at step 0;
+    [s0, v0, v1, s1] ramps from v0 at s0 to v1 at s1; longer lists [s0, v0, v1, s1, v2, s2, ...] chain further ramps.
+    The clock is `global_step` when the end step is an int and `epoch` when it is a float."""
     if isinstance(value, (int, float)):
         return value
-    value = list(value)
-    if len(value) == 3:
-        value = [0] + value
-    if len(value) >= 6:
-        select_i = 3
-        for i in range(3, len(value) - 2, 2):
-            if global_step >= value[i]:
-                select_i = i + 2
-        if select_i != 3:
-            start_value, start_step = value[select_i - 3], value[select_i - 2]
-        else:
-            start_step, start_value = value[:2]
-        end_value, end_step = value[select_i - 1], value[select_i]
-        value = [start_step, start_value, end_value, end_step]
-    assert len(value) == 4
-    start_step, start_value, end_value, end_step = value
-    current_step = global_step if isinstance(end_step, int) else epoch
-    t = max(min(1.0, (current_step - start_step) / (end_step - start_step)), 0.0)
+    spec = list(value)
+    if len(spec) == 3:
+        spec = [0] + spec
+    if len(spec) >= 6:
+        spec = list(_schedule_segment(spec, global_step))
+    if len(spec) != 4:
+        raise AssertionError(f"scheduled scalar needs 3, 4 or >= 6 elements, got {len(spec)}")
+    s0, v0, v1, s1 = spec
+    clock = global_step if isinstance(s1, int) else epoch
+    t = min(max((clock - s0) / (s1 - s0), 0.0), 1.0)
     if interpolation == "linear":
-        return start_value + (end_value - start_value) * t
+        return v0 + (v1 - v0) * t
     if interpolation == "exp":
-        return math.exp(math.log(start_value) * (1 - t) + math.log(end_value) * t)
+        return math.exp((1.0 - t) * math.log(v0) + t * math.log(v1))
     raise ValueError(f"Unknown interpolation method: {interpolation}")
 
 
 class Updateable:
-    def do_update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
-        for attr in self.__dir__():
-            if attr.startswith("_"):
+    """Mix-in of threestudio's step hooks (threestudio/utils/base.py:21-50): `do_update_step` / `do_update_step_end`
+    first recurse into every public attribute that is itself Updateable, then call the object's own hook."""
+
+    def _updateable_children(self):
+        for name in dir(self):
+            if name.startswith("_"):
                 continue
             try:
-                module = getattr(self, attr)
-            except Exception:
+                child = getattr(self, name)
+            except Exception:  # properties that are not ready yet (the reference swallows these too)
                 continue
-            if isinstance(module, Updateable):
-                module.do_update_step(epoch, global_step, on_load_weights=on_load_weights)
+            if isinstance(child, Updateable):
+                yield child
+
+    def do_update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        for child in self._updateable_children():
+            child.do_update_step(epoch, global_step, on_load_weights=on_load_weights)
         self.update_step(epoch, global_step, on_load_weights=on_load_weights)
 
     def do_update_step_end(self, epoch: int, global_step: int):
-        for attr in self.__dir__():
-            if attr.startswith("_"):
-                continue
-            try:
-                module = getattr(self, attr)
-            except Exception:
-                continue
-            if isinstance(module, Updateable):
-                module.do_update_step_end(epoch, global_step)
+        for child in self._updateable_children():
+            child.do_update_step_end(epoch, global_step)
         self.update_step_end(epoch, global_step)
 
     def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
