@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 13
+#define TT_ABI_VERSION 14
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -130,6 +130,10 @@ typedef struct {
                                   sensitivity; measured at the training shapes in tests/test_gpu_skip.py. */
     float skip_eps_geo;        /* the same for tt_render_bwd_geo on |d loss/d sdf| + |d loss/d sdf_grad|_1 per sample (dense
                                   under an eikonal loss, so usually nothing to skip there) */
+    const float* inv_std_dev;  /* null, or a DEVICE pointer to one float that replaces `inv_std` (clamped to [1e-6,1e6] in the
+                                  kernels like LearnedVariance.forward, renderer :34-35): trainable_variance=True
+                                  (renderer :53,82; neus_volume_renderer.py:26-37) without a host read-back per step.  Read
+                                  by tt_render_fwd / _bwd_geo, tt_march_fwd / _bwd and tt_render_eval */
 } tt_render_cfg;
 
 #define TT_R_PER_SAMPLE 1 /* also write per-sample sdf / sdf_grad / features (training extras, renderer :532-545) */
@@ -207,11 +211,12 @@ int tt_sample_uniform(int64_t n_rays, int32_t n_samples, float near_plane, float
  * (n_rays, K) at their mid-points (tt_decode_rays, flags = 0).  sigma = NeuS alpha over a fixed step / step,
  * T = exp(-exclusive_cumsum(sigma dt)), cdf = 1 - [T, 0]; F + 1 fine edges at the u_j of `placement` (u_jitter
  * (n_rays, F+1), U[0,1), or null = deterministic) through the piecewise-linear inverse cdf; out = the K + F + 2
- * edges merged in increasing order as out_t_starts/out_t_ends (n_rays, K + F + 1). */
+ * edges merged in increasing order as out_t_starts/out_t_ends (n_rays, K + F + 1).  inv_std_dev: null, or a device scalar
+ * that replaces inv_std (as tt_render_cfg.inv_std_dev). */
 int tt_sample_importance(const float* t_starts, const float* t_ends, const float* sdf, int64_t n_rays,
-                         int32_t n_proposal, int32_t n_fine, float inv_std, float render_step_size,
-                         const float* u_jitter, int32_t placement, float* out_t_starts, float* out_t_ends,
-                         void* stream);
+                         int32_t n_proposal, int32_t n_fine, float inv_std, const float* inv_std_dev,
+                         float render_step_size, const float* u_jitter, int32_t placement, float* out_t_starts,
+                         float* out_t_ends, void* stream);
 
 /* Forward render for explicit sample intervals.
  * rays_o, rays_d (n_rays,3); t_starts, t_ends (n_rays,S).
@@ -245,17 +250,21 @@ int tt_march_fwd(const float* rays_d, const float* t_starts, const float* t_ends
 
 /* Backward of tt_march_fwd down to the per-sample quantities: out_grad (n_rays*S,4) = (d/d sdf, d/d sdf_grad xyz),
  * upstream grads as in tt_render_bwd_geo (null = 0).  (d/d features = weights * g_rgb_fg * d sigmoid is formed inside
- * tt_render_bwd_tex.)  This is the `workspace` tt_render_bwd_geo fills for its decode backward. */
+ * tt_render_bwd_tex.)  This is the `workspace` tt_render_bwd_geo fills for its decode backward.
+ * g_inv_std_rays (n_rays, may be null; overwritten): d loss / d inv_std PER RAY (both logistic arguments of get_alpha are
+ * sdf estimates times inv_std, neus_volume_renderer.py:108-109); the caller sums the rays (fixed order: reproducible) and
+ * chains through its own parametrisation (LearnedVariance: inv_std = exp(10 p) clamped).  trainable_variance=True. */
 int tt_march_bwd(const float* rays_d, const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,
                  const float* opacity, const float* depth, const float* trans, const float* sdf,
                  const float* sdf_grad, const float* features, const float* g_opacity, const float* g_depth,
                  const float* g_rgb_fg, const float* g_z_variance, const float* g_normal_acc, const float* g_weights,
-                 const float* g_sdf, const float* g_sdf_grad, float* out_grad, void* stream);
+                 const float* g_sdf, const float* g_sdf_grad, float* g_inv_std_rays, float* out_grad, void* stream);
 
 /* Backward, geometry half: d/d(geometry planes 0..2) and d/d(sdf net).
  * Per-ray upstream grads (any may be null = 0): g_opacity, g_depth, g_rgb_fg(3), g_z_variance, g_normal_acc(3).
  * Per-sample upstream grads (null = 0): g_weights, g_sdf, g_sdf_grad(3).
  * Saved forward state: opacity, depth (per ray), trans, sdf, sdf_grad, features (per sample).
+ * g_inv_std_rays: as in tt_march_bwd (null unless the variance is trained).
  * workspace: n_rays*S*4 floats (written by the march backward, read by the decode backward).
  * grad_packed (P,6,H,W,32) and mlp grads are accumulated into (caller zero-fills).  The packed planes (= one copy of
  * grad_packed) must be smaller than 4 GB - 256 B (85 prompts of 256^2 planes), else TT_ERR_UNSUPPORTED -- the limit
@@ -265,8 +274,8 @@ int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, const float*
                       const float* depth, const float* trans, const float* sdf, const float* sdf_grad,
                       const float* features, const float* g_opacity, const float* g_depth, const float* g_rgb_fg,
                       const float* g_z_variance, const float* g_normal_acc, const float* g_weights,
-                      const float* g_sdf, const float* g_sdf_grad, float* workspace, float* grad_packed,
-                      const tt_mlp_grads* grads, void* stream);
+                      const float* g_sdf, const float* g_sdf_grad, float* g_inv_std_rays, float* workspace,
+                      float* grad_packed, const tt_mlp_grads* grads, void* stream);
 
 /* Backward, texture half: d/d(texture planes 3..5) and d/d(feature net).
  * Needs saved weights (per sample) and features; g_rgb_fg (per ray), g_features (per sample; null = 0). */

@@ -363,7 +363,7 @@ def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Seq
                    ray_indices=ray_indices, points=positions, alpha=alpha, trans=trans2d.reshape(-1, 1),
                    sdf=geo["sdf"], sdf_orig=geo["sdf_orig"], features=geo["features"],
                    normal=geo["normal"], shading_normal=geo["shading_normal"],
-                   sdf_grad=geo["sdf_grad"], inv_std=torch.tensor(inv_std))
+                   sdf_grad=geo["sdf_grad"], inv_std=torch.as_tensor(inv_std))
     return out
 
 

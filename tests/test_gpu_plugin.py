@@ -104,6 +104,70 @@ def test_training_render_through_plugin_backward(dev):
         assert w.grad is not None and torch.isfinite(w.grad).all()
 
 
+def test_trainable_variance_gradient_matches_oracle(dev):
+    """trainable_variance=True (the reference class default, generative_space_sdf_volume_renderer.py:53,82;
+    neus_volume_renderer.py:26-37): inv_std = exp(10 p) lives on the device, the kernels read it there, and
+    d loss / d p comes back through tt_render_bwd_geo's per-ray partials.  Checked against autograd through the oracle
+    (fp64 and fp32) with p as a leaf; every other gradient must equal the frozen-variance render's."""
+    torch.manual_seed(0)
+    g = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
+    m, b = tt.find("no-material")({}), tt.find("solid-color-background")({})
+    base = dict(estimator="importance", learned_variance_init=0.35, num_samples_per_ray=16,
+                num_samples_per_ray_importance=32, near_plane=0.1, far_plane=4.0)
+    rt = tt.find("generative-space-sdf-volume-renderer")(dict(base, trainable_variance=True), geometry=g, material=m,
+                                                         background=b).to(dev)
+    rf = tt.find("generative-space-sdf-volume-renderer")(dict(base, trainable_variance=False), geometry=g, material=m,
+                                                         background=b).to(dev)
+    rt.train(), rf.train()
+    gen = torch.Generator().manual_seed(5)
+    P, n_view, Hh, Ww, S = 1, 2, 5, 7, 40
+    cache0 = torch.randn(P, 6, 32, 32, 32, generator=gen) * 0.5
+    ro, rd, c2w, cd = O.make_cameras(P * n_view, Hh, Ww)
+    ts, te = O.uniform_intervals(P * n_view * Hh * Ww, S, 0.3, 3.2)
+    proj = {k: torch.randn(P * n_view, Hh, Ww, c, generator=gen) for k, c in (("comp_rgb", 3), ("opacity", 1), ("depth", 1))}
+
+    def run_hip(r):
+        cache = cache0.to(dev).requires_grad_(True)
+        for p_ in list(g.parameters()) + list(r.parameters()):
+            p_.grad = None
+        out = r(ro.to(dev), rd.to(dev), None, torch.ones(3, device=dev), space_cache=cache,
+                text_embed=torch.zeros(P, 77, 1024), camera_distances=cd.to(dev), c2w=c2w.to(dev), t_starts=ts.to(dev),
+                t_ends=te.to(dev))
+        loss = O.synthetic_loss(out, {k: v.to(dev) for k, v in proj.items()})
+        loss.backward()
+        return out, loss.item(), cache.grad.detach().cpu().double(), [w.grad.detach().cpu().double() for w in g.parameters()]
+
+    out_t, l_t, gc_t, gw_t = run_hip(rt)
+    gp = rt.variance._inv_std.grad.item()
+    out_f, l_f, gc_f, gw_f = run_hip(rf)
+    assert rf.variance._inv_std.grad is None
+    # same forward, same gradients of everything else (the device scalar is torch's fp32 exp(10 p), the host value the
+    # rounded double exp: they may differ in the last bit)
+    assert abs(l_t - l_f) <= 2e-5 * abs(l_f)
+    assert (gc_t - gc_f).norm() <= 1e-4 * gc_f.norm()
+    for a_, b_ in zip(gw_t, gw_f):
+        assert (a_ - b_).norm() <= 1e-4 * b_.norm()
+    assert out_t["inv_std"].requires_grad and abs(out_t["inv_std"].item() - float(rt.variance.inv_std)) < 1e-3
+
+    sw, fw = _weights(g)
+
+    def run_oracle(dtype):
+        p = torch.tensor(0.35, dtype=dtype, requires_grad=True)
+        inv_std = torch.exp(p * 10.0).clamp(1.0e-6, 1.0e6)
+        out = O.render(cache0.to(dtype), [w.to(dtype) for w in sw], [w.to(dtype) for w in fw], ro.to(dtype), rd.to(dtype),
+                       ts.to(dtype), te.to(dtype), torch.ones(3, dtype=dtype), cd.to(dtype), c2w.to(dtype), inv_std=inv_std)
+        loss = O.synthetic_loss(out, {k: v.to(dtype) for k, v in proj.items()})
+        return torch.autograd.grad(loss, [p])[0].item()
+
+    g64, g32 = run_oracle(torch.float64), run_oracle(torch.float32)
+    assert abs(gp - g32) <= 1e-4 * abs(g32) + 1e-7, (gp, g32, g64)      # north_star's rtol against the fp32 reference math
+    assert abs(gp - g64) <= max(3 * abs(g32 - g64), 1e-4 * abs(g64)), (gp, g32, g64)
+    # and the sampler reads the same device scalar: identical intervals from both renderers
+    a, _ = rt.sample(cache0.to(dev), ro.to(dev), rd.to(dev), generator=torch.Generator(device=dev).manual_seed(1))
+    b2, _ = rf.sample(cache0.to(dev), ro.to(dev), rd.to(dev), generator=torch.Generator(device=dev).manual_seed(1))
+    assert torch.allclose(a, b2, rtol=0, atol=1e-5)
+
+
 def test_patch_renderer_training_and_eval(dev):
     g, m, b, r, cfg = _build(dev)
     p = tt.find("patch-renderer")({"patch_size": 8, "global_downsample": 3,

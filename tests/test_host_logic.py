@@ -67,7 +67,10 @@ def test_renderer_construction_and_schedules():
     assert r.train().randomized is True and r.eval().randomized is False
     assert list(g.state_dict().keys())[1:] == [f"{n}.layers.{i}.weight" for n in ("sdf_network", "feature_network")
                                                 for i in (0, 2, 4)]
-    for bad in ({"estimator": "occgrid"}, {"use_volsdf": True}, {"trainable_variance": True}):
+    _, _, _, c = _modules({"trainable_variance": True})  # the reference class default (renderer :53,82): a trained parameter
+    rt = tt.find("generative-space-sdf-volume-renderer")(c, geometry=g, material=m, background=b)
+    assert rt.variance._inv_std.requires_grad and not r.variance._inv_std.requires_grad
+    for bad in ({"estimator": "occgrid"}, {"use_volsdf": True}):
         _, _, _, c = _modules(bad)
         with pytest.raises(NotImplementedError):
             tt.find("generative-space-sdf-volume-renderer")(c, geometry=g, material=m, background=b)
@@ -174,7 +177,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == _lib._expected_abi() == 13
+    assert lib.tt_abi_version() == _lib._expected_abi() == 14
     assert b"bad argument" in lib.tt_strerror(-1)
     # the binary carries the hash of the sources + flags it was built from, and that is what "up to date" means
     lib.tt_source_hash.restype = ctypes.c_char_p
@@ -268,7 +271,8 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert b"unsupported" in lib.tt_strerror(-2)
     # sampler placement enum: only TT_PLACE_TT (0) / TT_PLACE_CENTER (1)
     assert lib.tt_sample_uniform(4, 8, 0.1, 4.0, null, 2, one, one, null) == -1
-    assert lib.tt_sample_importance(one, one, one, 4, 8, 4, 100.0, 0.05, null, 7, one, one, null) == -1
+    assert lib.tt_sample_importance(one, one, one, 4, 8, 4, 100.0, null, 0.05, null, 7, one, one, null) == -1
+    assert lib.tt_sample_importance(one, one, one, 4, 8, 4, 0.0, null, 0.05, null, 0, one, one, null) == -1  # no inv_std at all
 
 
 def test_product_library_never_reads_the_environment():

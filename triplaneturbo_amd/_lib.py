@@ -202,7 +202,7 @@ class RenderCfg(ctypes.Structure):
         ("rays_per_view", _I32), ("n_samples", _I32), ("n_rays", _I64), ("radius", _F),
         ("sdf_bias_radius", _F), ("inv_std", _F), ("cos_anneal_ratio", _F), ("rgb_grad_shrink", _F),
         ("flags", _I32), ("image_w", _I32), ("tile_sb", _I32), ("grad_copies", _I32), ("tile_chunk", _I32),
-        ("skip_eps_tex", _F), ("skip_eps_geo", _F),
+        ("skip_eps_tex", _F), ("skip_eps_geo", _F), ("inv_std_dev", _P),
     ]
 
 
@@ -250,10 +250,10 @@ def load() -> ctypes.CDLL:
     lib.tt_query_field.argtypes = [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P]
     lib.tt_decode_rays.argtypes = [_P, _wp, _P, _P, _P, _P, _cfgp, _I32, _P, _P, _P, _P]
     optional = {
-        "tt_render_bwd_geo": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 14 + [_P, _P, _wp, _P],
+        "tt_render_bwd_geo": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 14 + [_P, _P, _P, _wp, _P],
         "tt_render_bwd_tex": [_P, _wp, _P, _P, _P, _P, _cfgp] + [_P] * 4 + [_P, _wp, _P],
         "tt_march_fwd": [_P, _P, _P, _cfgp] + [_P] * 11,
-        "tt_march_bwd": [_P, _P, _P, _cfgp] + [_P] * 16,
+        "tt_march_bwd": [_P, _P, _P, _cfgp] + [_P] * 17,
         "tt_points_bwd_geo": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _F, _I32, _P, _P, _P, _P, _wp, _P],
         "tt_points_bwd_tex": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _I32, _I32, _P, _P, _wp, _P],
         "tt_points_bwd_x": [_P, _wp, _P, _I32, _I64, _I32, _I32, _I32, _I32, _F, _I32, _P, _P, _P, _P, _P],
@@ -261,7 +261,7 @@ def load() -> ctypes.CDLL:
         "tt_hashgrid_fwd": [_P, _I64, _P, ctypes.POINTER(HashGridCfg), _P, _P],
         "tt_hashgrid_bwd": [_P, _I64, _P, ctypes.POINTER(HashGridCfg), _P, _P],
         "tt_sample_uniform": [_I64, _I32, _F, _F, _P, _I32, _P, _P, _P],
-        "tt_sample_importance": [_P, _P, _P, _I64, _I32, _I32, _F, _F, _P, _I32, _P, _P, _P],
+        "tt_sample_importance": [_P, _P, _P, _I64, _I32, _I32, _F, _P, _F, _P, _I32, _P, _P, _P],
         "tt_grid_sample_2d_grad2": [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
         "tt_grid_sample_2d_grad2_typed": [_I32] + [_P] * 5 + [_I32] * 4 + [_I64, _I32, _I32] + [_P] * 3 + [_P],
         "tt_debug_poison_queue": [_P],

@@ -327,8 +327,8 @@ int tt_launch_march_bwd(const float* rays_d, const float* t_starts, const float*
                         const float* sdf, const float* sdf_grad, const float* features, const float* trans,
                         const float* opacity, const float* depth, const float* g_opacity, const float* g_depth,
                         const float* g_rgb_fg, const float* g_z_variance, const float* g_normal_acc,
-                        const float* g_weights, const float* g_sdf, const float* g_sdf_grad, float* ws,
-                        hipStream_t stream);
+                        const float* g_weights, const float* g_sdf, const float* g_sdf_grad, float* g_inv_std_rays,
+                        float* ws, hipStream_t stream);
 
 extern "C" int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, const float* rays_o,
                                  const float* rays_d, const float* t_starts, const float* t_ends,
@@ -336,8 +336,8 @@ extern "C" int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, c
                                  const float* trans, const float* sdf, const float* sdf_grad, const float* features,
                                  const float* g_opacity, const float* g_depth, const float* g_rgb_fg,
                                  const float* g_z_variance, const float* g_normal_acc, const float* g_weights,
-                                 const float* g_sdf, const float* g_sdf_grad, float* workspace, float* grad_packed,
-                                 const tt_mlp_grads* grads, void* stream) {
+                                 const float* g_sdf, const float* g_sdf_grad, float* g_inv_std_rays, float* workspace,
+                                 float* grad_packed, const tt_mlp_grads* grads, void* stream) {
     int st = tt_validate_cfg(cfg);
     if (st != TT_OK) return st;
     if (!packed || !w || !rays_o || !rays_d || !t_starts || !t_ends || !opacity || !depth || !trans || !sdf ||
@@ -349,8 +349,8 @@ extern "C" int tt_render_bwd_geo(const float* packed, const tt_mlp_weights* w, c
     if (cus <= 0) return TT_ERR_DEVICE;
     hipStream_t s = (hipStream_t)stream;
     st = tt_launch_march_bwd(rays_d, t_starts, t_ends, cfg, sdf, sdf_grad, features, trans, opacity, depth, g_opacity,
-                             g_depth, g_rgb_fg, g_z_variance, g_normal_acc, g_weights, g_sdf, g_sdf_grad, workspace,
-                             s);
+                             g_depth, g_rgb_fg, g_z_variance, g_normal_acc, g_weights, g_sdf, g_sdf_grad, g_inv_std_rays,
+                             workspace, s);
     if (st != TT_OK) return st;
     BwdGeoParams p;
     p.packed = packed;

@@ -532,6 +532,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const int S = cfg.n_samples;
+    const float kstd = load_inv_std(cfg.inv_std_dev, cfg.inv_std);
     ItemQueue iq = item_queue(p.queue, tg.n_blocks, 1, tg.unit);
     const size_t plane_stride = (size_t)6 * cfg.plane_h * cfg.plane_w * TT_C;
     unsigned long long n_geo = 0, n_tex = 0;
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
             const float ux = gx * ign, uy = gy * ign, uz = gz * ign;
             const float cosv = dx * ux + dy * uy + dz * uz;
             // (select, not a product: a dead lane's alpha may be NaN -- it decodes nothing)
-            float alpha = neus_alpha_terms(sdf, cosv, te - ts, cfg.inv_std, cfg.cos_anneal_ratio).alpha;
+            float alpha = neus_alpha_terms(sdf, cosv, te - ts, kstd, cfg.cos_anneal_ratio).alpha;
             if (!live) alpha = 0.f;
             const float wgt = alpha * T;
             T *= 1.f - alpha;
@@ -737,7 +738,7 @@ int tt_validate_cfg(const tt_render_cfg* cfg) {
     if (cfg->n_rays != (int64_t)cfg->n_prompts * cfg->views_per_prompt * cfg->rays_per_view) return TT_ERR_BAD_ARG;
     if (cfg->plane_h <= 0 || cfg->plane_h != cfg->plane_w) return TT_ERR_UNSUPPORTED;
     if (tt_planes_too_large(cfg->n_prompts, cfg->plane_h, cfg->plane_w)) return TT_ERR_UNSUPPORTED;
-    if (!(cfg->radius > 0.f) || !(cfg->inv_std > 0.f)) return TT_ERR_BAD_ARG;
+    if (!(cfg->radius > 0.f) || (!cfg->inv_std_dev && !(cfg->inv_std > 0.f))) return TT_ERR_BAD_ARG;
     if (cfg->flags < 0) return TT_ERR_BAD_ARG;  // (the kernels use `flags >= 0` as an always-true opaque condition)
     if (!(cfg->skip_eps_tex >= 0.f) || !(cfg->skip_eps_geo >= 0.f)) return TT_ERR_BAD_ARG;
     return TT_OK;

@@ -26,6 +26,7 @@ struct MarchFwdParams {
     long long n_rays;
     int S;
     float inv_std, ratio;
+    const float* inv_std_dev;  // device scalar overriding inv_std (trainable variance), or null
     float* opacity;
     float* depth;
     float* rgb_fg;
@@ -116,14 +117,15 @@ struct FwdAcc {
     float T, op, d, r, g, b, nx, ny, nz;
 };
 // one 64-sample pass of a ray: returns this lane's (weight, transmittance, t mid-point)
-__device__ __forceinline__ void march_pass_fwd(const MarchFwdParams& p, const FwdIn& v, bool valid, int lane, float dx,
-                                               float dy, float dz, FwdAcc& a, float& wgt, float& Ti, float& tm) {
+__device__ __forceinline__ void march_pass_fwd(const MarchFwdParams& p, float kstd, const FwdIn& v, bool valid, int lane,
+                                               float dx, float dy, float dz, FwdAcc& a, float& wgt, float& Ti,
+                                               float& tm) {
     tm = (v.ts + v.te) / 2.f;
     const float gn = fmaxf(sqrtf(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz), 1e-12f);  // F.normalize eps
     const float ign = rcp_(gn);
     const float nx = v.gx * ign, ny = v.gy * ign, nz = v.gz * ign;
     const float cosv = dx * nx + dy * ny + dz * nz;
-    float alpha = neus_alpha_terms(v.sdf, cosv, v.te - v.ts, p.inv_std, p.ratio).alpha;
+    float alpha = neus_alpha_terms(v.sdf, cosv, v.te - v.ts, kstd, p.ratio).alpha;
     if (!valid) alpha = 0.f;
     float total;
     Ti = a.T * wave_excl_prod(1.f - alpha, total);
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) void k_march_fwd(MarchFwdParams p) {
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     const int S = p.S;
+    const float kstd = load_inv_std(p.inv_std_dev, p.inv_std);
     for (long long ray = wave; ray < p.n_rays; ray += n_waves) {
         const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
         FwdAcc a = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void k_march_fwd(MarchFwdParams p) {
             for (int k = 0; k < NP; ++k) {
                 const int si = 64 * k + lane;
                 float Ti;
-                march_pass_fwd(p, in[k], si < S, lane, dx, dy, dz, a, w[k], Ti, tmid[k]);
+                march_pass_fwd(p, kstd, in[k], si < S, lane, dx, dy, dz, a, w[k], Ti, tmid[k]);
                 if (si < S) {
                     p.weights[ray * S + si] = w[k];
                     p.trans[ray * S + si] = Ti;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void k_march_fwd(MarchFwdParams p) {
                 const long long sidx = ray * S + (valid ? si : 0);
                 const FwdIn v = march_load_fwd(p, sidx);
                 float wgt, Ti, tm;
-                march_pass_fwd(p, v, valid, lane, dx, dy, dz, a, wgt, Ti, tm);
+                march_pass_fwd(p, kstd, v, valid, lane, dx, dy, dz, a, wgt, Ti, tm);
                 if (valid) {
                     p.weights[sidx] = wgt;
                     p.trans[sidx] = Ti;
@@ -248,6 +251,8 @@ struct MarchBwdParams {
     long long n_rays;
     int S;
     float inv_std, ratio;
+    const float* inv_std_dev;  // device scalar overriding inv_std (trainable variance), or null
+    float* g_inv_std_rays;     // (n_rays) d loss / d inv_std per ray, or null
     float* ws;  // (n_rays*S, 4): d/d sdf, d/d sdf_grad xyz
 };
 
@@ -277,9 +282,8 @@ struct RayBar {  // per-ray upstream gradients and forward results
     float dx, dy, dz, op, D, b_op, b_d, b_z, b_r, b_g, b_b, b_nx, b_ny, b_nz;
 };
 // one 64-sample pass (passes run from the far end of the ray to the near end; Rcarry links them)
-__device__ __forceinline__ f32x4 march_pass_bwd(const MarchBwdParams& p, const BwdIn& v, bool valid, int lane,
-                                                const RayBar& rb, float& Rcarry) {
-    const float kstd = p.inv_std;
+__device__ __forceinline__ f32x4 march_pass_bwd(const MarchBwdParams& p, float kstd, const BwdIn& v, bool valid, int lane,
+                                                const RayBar& rb, float& Rcarry, float& dk) {
     const float tm = (v.ts + v.te) / 2.f;
     const float gn_raw = sqrtf(v.gx * v.gx + v.gy * v.gy + v.gz * v.gz);
     const float gn = fmaxf(gn_raw, 1e-12f);
@@ -305,7 +309,10 @@ __device__ __forceinline__ f32x4 march_pass_bwd(const MarchBwdParams& p, const B
     const float drat = dalpha * a.pass * (valid ? 1.f : 0.f);
     const float iden = rcp_(a.den);
     const float dnum = drat * iden, dden = -drat * a.rat * iden;
-    const float dA = (dnum + dden) * a.sA * (1.f - a.sA) * kstd, dB = (-dnum) * a.sB * (1.f - a.sB) * kstd;
+    const float dargA = (dnum + dden) * a.sA * (1.f - a.sA), dargB = (-dnum) * a.sB * (1.f - a.sB);
+    const float dA = dargA * kstd, dB = dargB * kstd;
+    // d loss / d inv_std of this sample: both logistic arguments are (estimated sdf) * inv_std  (neus...:108-109)
+    dk += dargA * a.prev_sdf + dargB * a.next_sdf;
     const float sbar = dA + dB;
     const float dcos = a.half * (dB - dA) * a.dic_dcos;
     const float nbx = wgt * rb.b_nx + dcos * rb.dx, nby = wgt * rb.b_ny + dcos * rb.dy,
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(256) void k_march_bwd(MarchBwdParams p) {
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     const int S = p.S;
+    const float kstd = load_inv_std(p.inv_std_dev, p.inv_std);
     for (long long ray = wave; ray < p.n_rays; ray += n_waves) {
         RayBar rb;
         rb.dx = p.rays_d[ray * 3 + 0];
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(256) void k_march_bwd(MarchBwdParams p) {
         rb.b_nx = p.g_nacc ? p.g_nacc[ray * 3 + 0] : 0.f;
         rb.b_ny = p.g_nacc ? p.g_nacc[ray * 3 + 1] : 0.f;
         rb.b_nz = p.g_nacc ? p.g_nacc[ray * 3 + 2] : 0.f;
-        float Rcarry = 0.f;
+        float Rcarry = 0.f, dk = 0.f;
         if constexpr (NP > 0) {
             BwdIn in[NP];
 #pragma unroll
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(256) void k_march_bwd(MarchBwdParams p) {
 #pragma unroll
             for (int k = NP - 1; k >= 0; --k) {
                 const int si = 64 * k + 63 - lane;
-                const f32x4 o = march_pass_bwd(p, in[k], si < S, lane, rb, Rcarry);
+                const f32x4 o = march_pass_bwd(p, kstd, in[k], si < S, lane, rb, Rcarry, dk);
                 if (si < S) *reinterpret_cast<f32x4*>(p.ws + (ray * S + si) * 4) = o;
             }
         } else {
@@ -368,9 +376,13 @@ __global__ __launch_bounds__(256) void k_march_bwd(MarchBwdParams p) {
                 const bool valid = si < S;
                 const long long sidx = ray * S + (valid ? si : 0);
                 const BwdIn v = march_load_bwd(p, sidx);
-                const f32x4 o = march_pass_bwd(p, v, valid, lane, rb, Rcarry);
+                const f32x4 o = march_pass_bwd(p, kstd, v, valid, lane, rb, Rcarry, dk);
                 if (valid) *reinterpret_cast<f32x4*>(p.ws + sidx * 4) = o;
             }
+        }
+        if (p.g_inv_std_rays) {  // trainable variance: one partial per ray, summed by the caller (deterministic)
+            dk = wave_sum(dk);
+            if (lane == 0) p.g_inv_std_rays[ray] = dk;
         }
     }
 }
@@ -397,6 +409,7 @@ int tt_launch_march_fwd(const float* rays_d, const float* t_starts, const float*
     p.n_rays = cfg->n_rays;
     p.S = cfg->n_samples;
     p.inv_std = cfg->inv_std;
+    p.inv_std_dev = cfg->inv_std_dev;
     p.ratio = cfg->cos_anneal_ratio;
     p.opacity = opacity;
     p.depth = depth;
@@ -421,8 +434,8 @@ int tt_launch_march_bwd(const float* rays_d, const float* t_starts, const float*
                         const float* sdf, const float* sdf_grad, const float* features, const float* trans,
                         const float* opacity, const float* depth, const float* g_opacity, const float* g_depth,
                         const float* g_rgb_fg, const float* g_z_variance, const float* g_normal_acc,
-                        const float* g_weights, const float* g_sdf, const float* g_sdf_grad, float* ws,
-                        hipStream_t stream) {
+                        const float* g_weights, const float* g_sdf, const float* g_sdf_grad, float* g_inv_std_rays,
+                        float* ws, hipStream_t stream) {
     MarchBwdParams p;
     p.rays_d = rays_d;
     p.t_starts = t_starts;
@@ -444,6 +457,8 @@ int tt_launch_march_bwd(const float* rays_d, const float* t_starts, const float*
     p.n_rays = cfg->n_rays;
     p.S = cfg->n_samples;
     p.inv_std = cfg->inv_std;
+    p.inv_std_dev = cfg->inv_std_dev;
+    p.g_inv_std_rays = g_inv_std_rays;
     p.ratio = cfg->cos_anneal_ratio;
     p.ws = ws;
     const dim3 grid(march_blocks(cfg->n_rays)), blk(256);
@@ -476,12 +491,12 @@ extern "C" int tt_march_bwd(const float* rays_d, const float* t_starts, const fl
                             const float* sdf_grad, const float* features, const float* g_opacity,
                             const float* g_depth, const float* g_rgb_fg, const float* g_z_variance,
                             const float* g_normal_acc, const float* g_weights, const float* g_sdf,
-                            const float* g_sdf_grad, float* out_grad, void* stream) {
+                            const float* g_sdf_grad, float* g_inv_std_rays, float* out_grad, void* stream) {
     int st = tt_validate_cfg(cfg);
     if (st != TT_OK) return st;
     if (!rays_d || !t_starts || !t_ends || !opacity || !depth || !trans || !sdf || !sdf_grad || !features || !out_grad)
         return TT_ERR_BAD_ARG;
     return tt_launch_march_bwd(rays_d, t_starts, t_ends, cfg, sdf, sdf_grad, features, trans, opacity, depth,
                                g_opacity, g_depth, g_rgb_fg, g_z_variance, g_normal_acc, g_weights, g_sdf, g_sdf_grad,
-                               out_grad, (hipStream_t)stream);
+                               g_inv_std_rays, out_grad, (hipStream_t)stream);
 }

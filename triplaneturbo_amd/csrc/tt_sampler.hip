@@ -62,6 +62,7 @@ struct ImportanceParams {
     int K, F;
     int placement;
     float inv_std, step;
+    const float* inv_std_dev;  // device scalar overriding inv_std (clamped to [1e-6, 1e6] like LearnedVariance), or null
     float* out_ts;  // (n_rays, K + F + 1)
     float* out_te;
 };
@@ -77,14 +78,15 @@ __global__ __launch_bounds__(256) void k_sample_importance(ImportanceParams p) {
     if (ray >= p.n_rays) return;  // wave-private LDS, no block barrier below
 
     // ---- proposal density -> transmittance -> cdf ----
+    const float kstd = p.inv_std_dev ? fminf(fmaxf(p.inv_std_dev[0], 1.0e-6f), 1.0e6f) : p.inv_std;
     float carry = 0.f;
     for (int base = 0; base < K; base += 64) {
         const int k = base + lane;
         const bool valid = k < K;
         const long long i = ray * K + (valid ? k : 0);
         const float ts = p.ts[i], te = p.te[i], sdf = p.sdf[i];
-        const float prev = sigmoidf_((sdf + p.step * 0.5f) * p.inv_std);
-        const float next = sigmoidf_((sdf - p.step * 0.5f) * p.inv_std);
+        const float prev = sigmoidf_((sdf + p.step * 0.5f) * kstd);
+        const float next = sigmoidf_((sdf - p.step * 0.5f) * kstd);
         const float alpha = fminf(fmaxf((prev - next + 1e-5f) / (prev + 1e-5f), 0.f), 1.f);
         const float sd = valid ? (alpha / p.step) * (te - ts) : 0.f;
         float inc = sd;
@@ -179,13 +181,13 @@ extern "C" int tt_sample_uniform(int64_t n_rays, int32_t n_samples, float near_p
 }
 
 extern "C" int tt_sample_importance(const float* t_starts, const float* t_ends, const float* sdf, int64_t n_rays,
-                                    int32_t n_proposal, int32_t n_fine, float inv_std, float render_step_size,
-                                    const float* u_jitter, int32_t placement, float* out_t_starts,
-                                    float* out_t_ends, void* stream) {
+                                    int32_t n_proposal, int32_t n_fine, float inv_std, const float* inv_std_dev,
+                                    float render_step_size, const float* u_jitter, int32_t placement,
+                                    float* out_t_starts, float* out_t_ends, void* stream) {
     if (!t_starts || !t_ends || !sdf || !out_t_starts || !out_t_ends || n_rays <= 0 || n_proposal <= 0 || n_fine <= 0)
         return TT_ERR_BAD_ARG;
     if (placement != TT_PLACE_TT && placement != TT_PLACE_CENTER) return TT_ERR_BAD_ARG;
-    if (!(inv_std > 0.f) || !(render_step_size > 0.f)) return TT_ERR_BAD_ARG;
+    if ((!inv_std_dev && !(inv_std > 0.f)) || !(render_step_size > 0.f)) return TT_ERR_BAD_ARG;
     const size_t lds = 4u * (2u * (n_proposal + 1) + (n_fine + 1)) * sizeof(float);
     if (lds > 64u * 1024u) return TT_ERR_UNSUPPORTED;
     if ((n_rays + 3) / 4 > 0x7fffffffLL) return TT_ERR_UNSUPPORTED;
@@ -199,6 +201,7 @@ extern "C" int tt_sample_importance(const float* t_starts, const float* t_ends, 
     p.F = n_fine;
     p.placement = placement;
     p.inv_std = inv_std;
+    p.inv_std_dev = inv_std_dev;
     p.step = render_step_size;
     p.out_ts = out_t_starts;
     p.out_te = out_t_ends;

@@ -166,5 +166,7 @@ def volume_render(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence
                                                           - rc.sdf_bias_radius)))
         out.set_lazy("normal", lazy(normal))
         out.set_lazy("shading_normal", lazy(normal))
-        out["inv_std"] = torch.full((), float(rc.inv_std), device=ro.device)  # fill kernel, no host-to-device copy
+        # (a fill kernel, no host-to-device copy; with a trained variance the renderer overwrites it with the graph tensor)
+        out["inv_std"] = (rc.inv_std_t.detach().reshape(()) if rc.inv_std_t is not None else
+                          torch.full((), float(rc.inv_std), device=ro.device))
     return out

@@ -6,6 +6,7 @@ happens in libtt_hip.so.  Tensors must be CUDA(=HIP) fp32; there is no CPU fallb
 from __future__ import annotations
 
 import ctypes
+import dataclasses
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -113,6 +114,11 @@ class RenderConfig:
     # threshold (tt_render_cfg.skip_eps_tex / skip_eps_geo in include/tt_abi.h; error measured in tests/test_gpu_skip.py)
     skip_eps_tex: float = 0.0
     skip_eps_geo: float = 0.0
+    # trainable variance (reference class default, renderer :53,82): a 0-dim CUDA tensor holding inv_std (e.g.
+    # exp(10 p).clamp(1e-6, 1e6)).  The kernels read it from the device (tt_render_cfg.inv_std_dev: no host read-back,
+    # legal under stream capture) and, when it requires grad, render_samples returns d loss / d inv_std through autograd.
+    # None = the host float `inv_std` above.
+    inv_std_t: Optional[Tensor] = None
 
 
 def planes_pack(space_cache: Tensor) -> Tensor:
@@ -335,13 +341,19 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
     if n_views * rays_per_view != n_rays or n_views % P != 0:
         raise ValueError(f"n_rays={n_rays} is not views*rays_per_view with views a multiple of P={P}")
     inv_std = min(max(float(rc.inv_std), 1.0e-6), 1.0e6)  # LearnedVariance.forward clamp, renderer :34-35
+    inv_std_dev = None
+    if rc.inv_std_t is not None:
+        t = _chk(rc.inv_std_t, "inv_std_t")
+        if t.numel() != 1:
+            raise ValueError("inv_std_t must hold one float")
+        inv_std_dev = t.data_ptr()  # (the tensor is kept alive by `rc`, which the callers hold across the launch)
     return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
                           inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
                           (_lib.TT_R_PER_SAMPLE if per_sample else 0) | (_lib.TT_R_EXACT_F32 if rc.exact_f32 else 0) |
                           (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0),
                           image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0, int(rc.tile_sb),
                           max(1, int(rc.grad_copies)), max(0, int(rc.tile_chunk)), max(0.0, float(rc.skip_eps_tex)),
-                          max(0.0, float(rc.skip_eps_geo)))
+                          max(0.0, float(rc.skip_eps_geo)), inv_std_dev)
 
 
 def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
@@ -440,10 +452,14 @@ def sample_uniform(n_rays: int, n_samples: int, near: float, far: float, device,
 
 @torch.no_grad()
 def sample_importance(t_starts: Tensor, t_ends: Tensor, sdf: Tensor, n_fine: int, inv_std: float,
-                      render_step_size: float, u_jitter: Optional[Tensor] = None, placement: str = "tt"):
+                      render_step_size: float, u_jitter: Optional[Tensor] = None, placement: str = "tt",
+                      inv_std_t: Optional[Tensor] = None):
     """tt_sample_importance: proposal intervals (n_rays, K) + sdf at their mid-points -> (n_rays, K + n_fine + 1)
-    intervals (proposal edges merged with n_fine + 1 inverse-CDF edges placed per `placement`)."""
+    intervals (proposal edges merged with n_fine + 1 inverse-CDF edges placed per `placement`).  inv_std_t: a 0-dim
+    CUDA tensor that replaces the host float (trainable variance)."""
     place = _placement(placement)
+    if inv_std_t is not None:
+        inv_std_t = _chk(inv_std_t.detach(), "inv_std_t")
     t_starts, t_ends, sdf = _chk(t_starts, "t_starts"), _chk(t_ends, "t_ends"), _chk(sdf, "sdf")
     n_rays, K = t_starts.shape
     if t_ends.shape != (n_rays, K) or sdf.numel() != n_rays * K:
@@ -457,7 +473,8 @@ def sample_importance(t_starts: Tensor, t_ends: Tensor, sdf: Tensor, n_fine: int
     ots, ote = torch.empty((n_rays, M), **f32), torch.empty((n_rays, M), **f32)
     with _timed("tt_sample_importance"):
         st = _lib.load().tt_sample_importance(_ptr(t_starts), _ptr(t_ends), _ptr(sdf), n_rays, K, int(n_fine),
-                                              float(inv_std), float(render_step_size), _ptr(u_jitter), place,
+                                              float(inv_std), _ptr(inv_std_t), float(render_step_size),
+                                              _ptr(u_jitter), place,
                                               _ptr(ots), _ptr(ote), _stream())
     _lib.check(st, "tt_sample_importance")
     return ots, ote
@@ -477,7 +494,8 @@ def march_forward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, sdf: Ten
     cfg = _lib.RenderCfg(n_prompts=1, views_per_prompt=1, plane_h=1, plane_w=1, rays_per_view=n_rays, n_samples=S,
                          n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=rc.inv_std,
                          cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink, flags=0, image_w=0,
-                         tile_sb=0, grad_copies=1, tile_chunk=0)
+                         tile_sb=0, grad_copies=1, tile_chunk=0,
+                         inv_std_dev=None if rc.inv_std_t is None else rc.inv_std_t.data_ptr())
     f32 = dict(device=rays_d.device, dtype=torch.float32)
     if out is None:
         out = {"opacity": torch.empty((n_rays, 1), **f32), "depth": torch.empty((n_rays, 1), **f32),
@@ -497,14 +515,16 @@ def march_forward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, sdf: Ten
 def march_backward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, fwd: dict, sdf: Tensor, sdf_grad: Tensor,
                        features: Tensor, rc: RenderConfig, g_opacity=None, g_depth=None, g_rgb_fg=None,
                        g_z_variance=None, g_normal_acc=None, g_weights=None, g_sdf=None, g_sdf_grad=None,
-                       out: Optional[Tensor] = None):
+                       out: Optional[Tensor] = None, g_inv_std_rays: Optional[Tensor] = None):
     """tt_march_bwd: (n_rays*S, 4) = (d/d sdf, d/d sdf_grad) from upstream gradients of the march outputs; `fwd` is
-    the dict march_forward_raw / render_forward_raw returned (opacity, depth, trans)."""
+    the dict march_forward_raw / render_forward_raw returned (opacity, depth, trans).  g_inv_std_rays (n_rays), if
+    given, receives d loss / d inv_std per ray."""
     n_rays, S = t_starts.shape
     cfg = _lib.RenderCfg(n_prompts=1, views_per_prompt=1, plane_h=1, plane_w=1, rays_per_view=n_rays, n_samples=S,
                          n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=rc.inv_std,
                          cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink, flags=0, image_w=0,
-                         tile_sb=0, grad_copies=1, tile_chunk=0)
+                         tile_sb=0, grad_copies=1, tile_chunk=0,
+                         inv_std_dev=None if rc.inv_std_t is None else rc.inv_std_t.data_ptr())
     if out is None:
         out = torch.empty((n_rays * S, 4), device=rays_d.device, dtype=torch.float32)
     c = lambda t: None if t is None else t.contiguous()
@@ -512,7 +532,8 @@ def march_backward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, fwd: di
     with _timed("tt_march_bwd"):
         st = _lib.load().tt_march_bwd(_ptr(rays_d), _ptr(t_starts), _ptr(t_ends), ctypes.byref(cfg),
                                       _ptr(fwd["opacity"]), _ptr(fwd["depth"]), _ptr(fwd["trans"]), _ptr(sdf),
-                                      _ptr(sdf_grad), _ptr(features), *[_ptr(t) for t in gs], _ptr(out), _stream())
+                                      _ptr(sdf_grad), _ptr(features), *[_ptr(t) for t in gs], _ptr(g_inv_std_rays),
+                                      _ptr(out), _stream())
     _lib.check(st, "tt_march_bwd")
     return out
 
@@ -539,8 +560,11 @@ class _TriplaneRenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, packed, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, rays_per_view, rc,
-                image_w):
-        need_grad = any(ctx.needs_input_grad[:7])
+                image_w, inv_std_t=None):
+        # inv_std_t: rc.inv_std_t again, as an autograd INPUT (trainable variance: its gradient is returned below)
+        need_grad = any(ctx.needs_input_grad[:7]) or ctx.needs_input_grad[14]
+        if inv_std_t is not None:  # keep a graph-free alias on ctx (same storage), not the autograd input itself
+            rc = dataclasses.replace(rc, inv_std_t=inv_std_t.detach())
         ctx.set_materialize_grads(False)  # unused outputs (e.g. `features`, `weights`) reach backward as None, not as
         #                                    100 MB of zeros the kernels would have to read
         raw = render_forward_raw(packed, (w1, w2, w3), (v1, v2, v3), rays_o, rays_d, t_starts, t_ends, rays_per_view,
@@ -548,6 +572,7 @@ class _TriplaneRenderFn(torch.autograd.Function):
         ctx.rays_per_view = rays_per_view
         ctx.rc = rc
         ctx.image_w = image_w
+        ctx.inv_std_shape = None if inv_std_t is None else tuple(inv_std_t.shape)
         if need_grad:
             ctx.save_for_backward(packed, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, raw["opacity"],
                                   raw["depth"], raw["trans"], raw["weights"], raw["features"], raw["sdf"],
@@ -576,12 +601,16 @@ class _TriplaneRenderFn(torch.autograd.Function):
         g_op, g_depth, g_rgb, g_zvar, g_nacc = c(g_op), c(g_depth), c(g_rgb), c(g_zvar), c(g_nacc)
         g_weights, g_sdf, g_sdf_grad, g_features = c(g_weights), c(g_sdf), c(g_sdf_grad), c(g_features)
         lib = _lib.load()
+        g_k_rays = None
+        if ctx.needs_input_grad[14]:  # d loss / d inv_std, one partial per ray (summed below in a fixed order)
+            g_k_rays = torch.empty((n_rays,), device=packed.device, dtype=torch.float32)
         with _timed("tt_render_bwd_geo"):
             st = lib.tt_render_bwd_geo(
                 _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
                 ctypes.byref(cfg), _ptr(opacity), _ptr(depth), _ptr(trans), _ptr(sdf), _ptr(sdf_grad),
                 _ptr(features), _ptr(g_op), _ptr(g_depth), _ptr(g_rgb), _ptr(g_zvar), _ptr(g_nacc), _ptr(g_weights),
-                _ptr(g_sdf), _ptr(g_sdf_grad), _ptr(workspace), _ptr(grad_packed), ctypes.byref(gst), _stream())
+                _ptr(g_sdf), _ptr(g_sdf_grad), _ptr(g_k_rays), _ptr(workspace), _ptr(grad_packed), ctypes.byref(gst),
+                _stream())
         _lib.check(st, "tt_render_bwd_geo")
         with _timed("tt_render_bwd_tex"):
             st = lib.tt_render_bwd_tex(
@@ -592,7 +621,10 @@ class _TriplaneRenderFn(torch.autograd.Function):
         g_packed = None
         if ctx.needs_input_grad[0]:
             g_packed = grad_packed[0] if copies == 1 else grad_packed.sum(dim=0)
-        return (g_packed, *gw, None, None, None, None, None, None, None)
+        g_inv_std = None
+        if g_k_rays is not None:
+            g_inv_std = g_k_rays.double().sum().float().reshape(ctx.inv_std_shape)
+        return (g_packed, *gw, None, None, None, None, None, None, None, g_inv_std)
 
 
 def render_samples(space_cache: Optional[Tensor], sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
@@ -607,7 +639,7 @@ def render_samples(space_cache: Optional[Tensor], sdf_w: Sequence[Tensor], feat_
         packed = pack_planes(space_cache)
     outs = _TriplaneRenderFn.apply(packed, sdf_w[0], sdf_w[1], sdf_w[2], feat_w[0], feat_w[1], feat_w[2],
                                    rays_o.contiguous(), rays_d.contiguous(), t_starts.contiguous(),
-                                   t_ends.contiguous(), rays_per_view, rc, int(image_w))
+                                   t_ends.contiguous(), rays_per_view, rc, int(image_w), rc.inv_std_t)
     return dict(zip(names, outs))
 
 

@@ -106,14 +106,13 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
             raise NotImplementedError("estimator must be 'importance' (the reference raises for 'occgrid', :83-85)")
         if c.use_volsdf:
             raise NotImplementedError("use_volsdf=True is not part of the accelerated path (yaml :135)")
-        if c.trainable_variance:
-            raise NotImplementedError("trainable_variance=False only (yaml :136 'important!'): the kernels take "
-                                      "inv_std as a constant")
         assert c.normal_direction in ["front", "camera", "world"]
         self.geometry, self.material, self.background = geometry, material, background
         if material is not None and not isinstance(material, NoMaterial):
             raise NotImplementedError("the fused path implements NoMaterial (sigmoid-mipnerf) only")
-        self.variance = LearnedVariance(c.learned_variance_init, requires_grad=False)
+        # trainable_variance=True (the reference CLASS default, :53,82; the yaml switches it off, :136): the kernels read
+        # inv_std from the device and tt_render_bwd_geo returns d loss / d inv_std (ops.RenderConfig.inv_std_t)
+        self.variance = LearnedVariance(c.learned_variance_init, requires_grad=bool(c.trainable_variance))
         self.render_step_size = 1.732 * 2 * c.radius / c.num_samples_per_ray  # neus_volume_renderer.py:84-86
         self.cos_anneal_ratio = 1.0
         self.randomized = c.randomized
@@ -166,10 +165,17 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
 
     def _render_config(self) -> ops.RenderConfig:
         g = self.geometry.cfg
-        return ops.RenderConfig(radius=self.cfg.radius, sdf_bias_radius=float(g.sdf_bias_params),
-                                inv_std=self._inv_std_value(), cos_anneal_ratio=float(self.cos_anneal_ratio),
-                                rgb_grad_shrink=float(self.rgb_grad_shrink), skip_eps_tex=float(self.grad_skip_eps_tex),
-                                skip_eps_geo=float(self.grad_skip_eps_geo))
+        rc = ops.RenderConfig(radius=self.cfg.radius, sdf_bias_radius=float(g.sdf_bias_params),
+                              cos_anneal_ratio=float(self.cos_anneal_ratio),
+                              rgb_grad_shrink=float(self.rgb_grad_shrink), skip_eps_tex=float(self.grad_skip_eps_tex),
+                              skip_eps_geo=float(self.grad_skip_eps_geo))
+        if self.cfg.trainable_variance:
+            # LearnedVariance.forward's value as a graph tensor on the device (renderer :29-35): the optimiser moves the
+            # parameter every step, so nothing is read back to the host; rc.inv_std stays a placeholder the kernels ignore
+            rc.inv_std_t = self.variance.inv_std.clamp(1.0e-6, 1.0e6).float()
+        else:
+            rc.inv_std = self._inv_std_value()
+        return rc
 
     def sample(self, space_cache: Tensor, rays_o: Tensor, rays_d: Tensor, generator=None, packed=None):
         """ImportanceEstimator.sampling + prop_sigma_fn (estimators.py:22-101, renderer :243-316), no grad."""
@@ -188,7 +194,8 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         return sampler.importance_sampling(
             sdf_fn, n_rays, self.cfg.num_samples_per_ray_importance, self.cfg.num_samples_per_ray,
             self.cfg.near_plane, self.cfg.far_plane, rc.inv_std, self.render_step_size, device=rays_o.device,
-            stratified=self.randomized, generator=generator, placement=self.sampler_placement)
+            stratified=self.randomized, generator=generator, placement=self.sampler_placement,
+            inv_std_t=rc.inv_std_t)
 
     def forward(self, rays_o: Tensor, rays_d: Tensor, light_positions: Optional[Tensor] = None,
                 bg_color: Optional[Tensor] = None, noise: Optional[Tensor] = None,
