@@ -19,6 +19,7 @@ recomputed from profiles/ with the arithmetic in profiles/README.md.
 """
 import argparse
 import csv
+import dataclasses
 import glob
 import json
 import os
@@ -67,11 +68,11 @@ PEAK_F32_TFLOPS = 157.3     # dense fp32-input MFMA = fp32 vector peak (MI355X_M
 PEAK_F16_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
 PEAK = {"f32": PEAK_F32_TFLOPS, "valu": PEAK_F32_TFLOPS, "f16x3": PEAK_F16_TFLOPS / 3.0, "f16x4": PEAK_F16_TFLOPS / 4.0}
 PEAK_HBM_GBS = 8000.0
-DTYPE = "f32 (2xfp16-split products, 22-bit)"
+DTYPE = "f32 (2xfp16-split products, RNE split: ~24-bit)"
 DTYPE_EXACT = "f32 (fp32-input MFMA)"
 
 
-def kernel_roofline(name, ms, n_samples, exact, wgrad_f32=False):
+def kernel_roofline(name, ms, n_samples, exact, wgrad_f32=False, work=None):
     """Both forms of  max(algorithmic bytes / HBM peak, algorithmic FLOP / MFMA peak) / measured time :
       frac_8d       SURVEY 8(d) literally: bytes_8d / 8 TB/s against ALL algorithmic FLOP / 157.3 TFLOP/s (the fp32-MFMA
                     roofline 8(d) names).  A value > 1 means the kernel beats both 8(d) ceilings -- possible because the
@@ -89,7 +90,21 @@ def kernel_roofline(name, ms, n_samples, exact, wgrad_f32=False):
     t_hbm = a["bytes_8d"] * n_samples / (PEAK_HBM_GBS * 1e9) * 1e3                       # ms at 8 TB/s
     t_f32 = flop / (PEAK_F32_TFLOPS * 1e12) * 1e3                                         # ms at 157.3 TFLOP/s
     t_mix = sum(2.0 * m * n_samples / (PEAK[p] * 1e12) for p, m in macs.items()) * 1e3    # ms at each pipe's peak
+    extra = {}
+    if work is not None:
+        # what the kernel EXECUTED (device counters, tt_render_cfg.stats): a 32-sample tile step without an in-bounds
+        # texel (and, in the backward, without a non-zero upstream gradient) is skipped exactly -- its FLOPs are not
+        # done; a (plane, sample) pair outside the plane touches no texel -- its bytes are not moved
+        live, inb = work["live_tile_frac"], work["inbounds_plane_frac"]
+        extra = {"live_tile_frac": round(live, 4), "inbounds_plane_frac": round(inb, 4),
+                 "tile_steps_visited": work["visited"], "tile_steps_executed": work["executed"],
+                 "executed_tflops": round(flop * live / (ms * 1e-3) / 1e12, 2),
+                 "executed_GBs": round(a["bytes_8d"] * n_samples * inb / (ms * 1e-3) / 1e9, 1),
+                 "frac_8d_executed": round(max(t_hbm * inb, t_f32 * live) / ms, 4),
+                 "frac_pipe_mix_executed": round(max(t_hbm * inb, t_mix * live) / ms, 4),
+                 "ns_per_executed_tile_step": round(ms * 1e6 / max(work["executed"], 1), 3)}
     return {
+        **extra,
         "avg_ms": round(ms, 4), "alg_bytes_per_sample": a["bytes_8d"], "alg_flop_per_sample": int(flop_per_sample),
         "alg_GBs": round(a["bytes_8d"] * n_samples / (ms * 1e-3) / 1e9, 1),
         "alg_tflops": round(flop / (ms * 1e-3) / 1e12, 2),
@@ -227,40 +242,57 @@ def march_roofline(inp, rc, ops, reps):
             "note": "algorithmic bytes per sample (44 fwd / 68 bwd) x samples per launch over the HIP-event duration"}
 
 
-# ---- HBM-side traffic of the kernels: two separate rocprofv3 --pmc passes over a short run of this same script ---------
-def pmc_traffic(config, timeout_s=240):
-    """FETCH_SIZE and WRITE_SIZE (TCC) per kernel launch, each in its OWN `rocprofv3 --pmc <counter> --kernel-trace` pass
-    (they do not fit one pass: MI355X_MICROARCH.md, rocprofv3 PMC slots) over `bench.py --pmc-child` (3 steps).  Bytes =
-    (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KiB, and on gfx950 FETCH_SIZE reports half of a wide
-    coalesced read (same guide; calibrated in this workload on k_planes_pack: 50.3 MB read + 50.3 MB written)."""
+# ---- rocprofv3 --pmc passes over a short run of this same script (each pass = its own process, counters only) --------
+SQ_PASS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_ACTIVE_INST_VALU",
+           "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY"]
+
+
+def pmc_pass(counters, config, timeout_s=240):
+    """One `rocprofv3 --pmc <counters> --kernel-trace` pass over `bench.py --pmc-child` (2 steps after 1 warm-up):
+    returns {counter: {kernel: average value per launch}}, or (None, reason)."""
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="tt_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc"] + list(counters) + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                                            os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(config),
+                                            "--steps", "2", "--warmup", "1"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        shutil.rmtree(d, ignore_errors=True)
+        return None, f"rocprofv3 --pmc {' '.join(counters)} timed out"
+    acc, cnt = {}, {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            c = row["Counter_Name"]
+            if c not in counters:
+                continue
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+            acc.setdefault(c, {})
+            cnt.setdefault(c, {})
+            acc[c][k] = acc[c].get(k, 0.0) + float(row["Counter_Value"])
+            cnt[c][k] = cnt[c].get(k, 0) + 1
+    shutil.rmtree(d, ignore_errors=True)
+    if not acc:
+        return None, f"rocprofv3 --pmc {' '.join(counters)} produced no counters (rc {r.returncode}): {r.stderr[-300:]}"
+    return {c: {k: acc[c][k] / cnt[c][k] for k in acc[c]} for c in acc}, None
+
+
+def pmc_traffic(config):
+    """FETCH_SIZE and WRITE_SIZE (TCC) per kernel launch, each in its OWN pass (they do not fit one pass:
+    MI355X_MICROARCH.md, rocprofv3 PMC slots).  Bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KiB,
+    and on gfx950 FETCH_SIZE reports half of a wide coalesced read (same guide; calibrated in this workload on
+    k_planes_pack: 50.3 MB read + 50.3 MB written)."""
     per = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="tt_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(config), "--steps", "2", "--warmup", "1"]
-        env = dict(os.environ, TMPDIR="/tmp")
-        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
-            env.pop(k, None)
-        try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
-        except subprocess.TimeoutExpired:
-            shutil.rmtree(d, ignore_errors=True)
-            return None, f"rocprofv3 --pmc {ctr} timed out"
-        acc, cnt = {}, {}
-        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            for row in csv.DictReader(open(f)):
-                if row["Counter_Name"] != ctr:
-                    continue
-                k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
-                acc[k] = acc.get(k, 0.0) + float(row["Counter_Value"])
-                cnt[k] = cnt.get(k, 0) + 1
-        shutil.rmtree(d, ignore_errors=True)
-        if not acc:
-            return None, f"rocprofv3 --pmc {ctr} produced no counters (rc {r.returncode}): {r.stderr[-300:]}"
-        per[ctr] = {k: acc[k] / cnt[k] for k in acc}
+        res, err = pmc_pass([ctr], config)
+        if res is None:
+            return None, err
+        per[ctr] = res.get(ctr, {})
     out = {}
     for k in per["FETCH_SIZE"]:
         if k in per["WRITE_SIZE"]:
@@ -269,8 +301,182 @@ def pmc_traffic(config, timeout_s=240):
     return out, None
 
 
+def pmc_pipes(config):
+    """What the SIMDs did, per kernel launch, from ONE pass of SQ counters (7 of the 8 SQ slots), as ratios that need no
+    clock: kernel cycles = SQ_BUSY_CYCLES / 32 shader engines; 1024 SIMDs.
+      mfma_util       SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024)   -- north_star's MFMA utilisation
+      valu_util       SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES                -- share of a wave's life issuing VALU (incl. MFMA)
+      issue_util      SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES
+      wait_any        SQ_WAIT_ANY / SQ_WAVE_CYCLES                        -- wave parked on s_waitcnt / barrier
+      waves_per_simd  4 SQ_WAVE_CYCLES / (kernel cycles x 1024)           -- average resident waves per SIMD"""
+    res, err = pmc_pass(SQ_PASS, config)
+    if res is None:
+        return None, err
+    out = {}
+    for k in res.get("SQ_BUSY_CYCLES", {}):
+        g = lambda c: res.get(c, {}).get(k, 0.0)
+        cyc = g("SQ_BUSY_CYCLES") / 32.0
+        wc = g("SQ_WAVE_CYCLES")
+        if cyc <= 0 or wc <= 0:
+            continue
+        out[k] = {"mfma_util": round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (cyc * 1024.0), 4),
+                  "valu_util": round(g("SQ_ACTIVE_INST_VALU") / wc, 4),
+                  "issue_util": round(g("SQ_ACTIVE_INST_ANY") / wc, 4), "wait_any": round(g("SQ_WAIT_ANY") / wc, 4),
+                  "waves_per_simd": round(4.0 * wc / (cyc * 1024.0), 3), "kernel_cycles": int(cyc),
+                  "mfma_busy_cycles": int(g("SQ_VALU_MFMA_BUSY_CYCLES")), "waves": int(g("SQ_WAVES"))}
+    return out, None
+
+
+STAT_ROWS = {"tt_render_fwd": 0, "tt_render_bwd_geo": 1, "tt_render_bwd_tex": 2}
+
+
+def work_fractions(stats, n_samples):
+    """stats: the (3, 4) int64 tensor the decode kernels added to during ONE step (ops.RenderConfig.stats)."""
+    st = stats.cpu().tolist()
+    out = {}
+    for name, r in STAT_ROWS.items():
+        visited, executed, inb = st[r][0], st[r][1], st[r][2]
+        out[name] = {"visited": visited, "executed": executed,
+                     "live_tile_frac": executed / max(visited, 1), "inbounds_plane_frac": inb / (3.0 * n_samples)}
+    return out
+
+
+def cube_intervals(ro, rd, S, near, far, half=0.999):
+    """Uniform intervals clipped per ray to the plane cube [-half, half]^3 (slab test): every sample of a ray that hits
+    the cube lies inside it, so no tile step is skipped -- the `dense_scene` workload.  Rays that miss keep [near, far]."""
+    o, d = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    inv = 1.0 / torch.where(d.abs() < 1e-9, torch.full_like(d, 1e-9), d)
+    t1, t2 = (-half - o) * inv, (half - o) * inv
+    tn = torch.minimum(t1, t2).max(dim=-1).values.clamp_min(near)
+    tf = torch.maximum(t1, t2).min(dim=-1).values.clamp_max(far)
+    hit = tf > tn + 1e-4
+    tn = torch.where(hit, tn, torch.full_like(tn, near))
+    tf = torch.where(hit, tf, torch.full_like(tf, far))
+    edges = tn[:, None] + (tf - tn)[:, None] * torch.linspace(0.0, 1.0, S + 1, device=o.device)[None, :]
+    return edges[:, :-1].contiguous(), edges[:, 1:].contiguous(), float(hit.float().mean())
+
+
+def grad_error(got, ref):
+    """norm-wise relative error and SURVEY 8(d)'s element-wise bar (|a-b| <= 1e-4 |b| + 1e-6 max|b|) of one gradient"""
+    a, b = got.detach().double().reshape(-1), ref.detach().double().reshape(-1)
+    allow = 1e-4 * b.abs() + 1e-6 * b.abs().max().clamp_min(1e-300)
+    return {"rel_norm": float((a - b).norm() / b.norm().clamp_min(1e-300)),
+            "elem_viol_frac": float(((a - b).abs() > allow).double().mean())}
+
+
 # ---- SURVEY 8(d) secondary (reference-faithful) workloads, outside the timed region ----------------------------------
-def secondary_workloads(device, inp, steps=5, warmup=2):
+def dense_scene(device, inp, rc, steps=20, warmup=3):
+    """configs[1] with every ray's samples clipped to the plane cube: no tile step can be skipped, so the kernels' cost per
+    EXECUTED sample is on record next to the headline scene (where ~18 % of the tile steps are empty space)."""
+    import dataclasses
+    from triplaneturbo_amd import functional, ops
+    S = inp["ts"].shape[1]
+    ts, te, hit = cube_intervals(inp["ro"], inp["rd"], S, 0.1, 4.0)
+    params = [inp["cache"]] + inp["sw"] + inp["fw"]
+
+    def step(rcfg):
+        for t in params:
+            t.grad = None
+        out = functional.volume_render(inp["cache"], inp["sw"], inp["fw"], inp["ro"], inp["rd"], ts, te, inp["bg"],
+                                       inp["cd"], inp["c2w"], rcfg, training=True)
+        loss_fn(out, inp["proj"], fused_eikonal=True).backward()
+
+    for _ in range(warmup):
+        step(rc)
+    timer = ops.KernelTimer()
+    ops.set_kernel_timer(timer)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(rc)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ops.set_kernel_timer(None)
+    stats = torch.zeros((3, 4), dtype=torch.int64, device=device)
+    step(dataclasses.replace(rc, stats=stats))
+    torch.cuda.synchronize()
+    n_samples = ts.numel()
+    work = work_fractions(stats, n_samples)
+    kern = {k: kernel_roofline(k, v[0], n_samples, rc.exact_f32, rc.wgrad_f32, work=work[k])
+            for k, v in timer.summary(median=True).items() if k in ALG}
+    for t in params:
+        t.grad = None
+    return {"workload": "configs[1] planes / camera / loss, the 128 uniform samples of every ray clipped to the plane cube "
+                        "(slab test, half-width 0.999): all samples in bounds on the rays that hit it",
+            "rays_hitting_cube": round(hit, 4), "steps": steps, "ms_per_step": round(ms, 3),
+            "rays_per_s": round(ts.shape[0] / (ms * 1e-3), 1), "kernels": kern}
+
+
+def skip_workloads(device, inp, rc, train_step, train_params, steps=10):
+    """The OPT-IN backward skip (tt_render_cfg.skip_eps_tex; default 0 = exact, what `value` is measured with): ms per step
+    and the induced gradient error against the exact run, on the headline scene and on the training shape."""
+    import dataclasses
+    from triplaneturbo_amd import functional, ops
+    params = [inp["cache"]] + inp["sw"] + inp["fw"]
+    names = ["planes_tex", "feat.v1", "feat.v2", "feat.v3"]
+
+    def bench_step(rcfg):
+        for t in params:
+            t.grad = None
+        out = functional.volume_render(inp["cache"], inp["sw"], inp["fw"], inp["ro"], inp["rd"], inp["ts"], inp["te"],
+                                       inp["bg"], inp["cd"], inp["c2w"], rcfg, training=True)
+        loss_fn(out, inp["proj"], fused_eikonal=True).backward()
+        return out
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    def tex_grads(ps):
+        return [ps[0].grad[:, 3:].clone()] + [t.grad.clone() for t in ps[4:7]]
+
+    res = {"note": "thresholds relative to the launch's largest |cbar|_1 (cbar = d loss / d raw feature); errors of the "
+                   "texture-plane / feature-net gradients against the exact (eps = 0) run of the same inputs: norm-wise and "
+                   "the fraction of elements outside SURVEY 8(d)'s bar; geometry gradients are untouched"}
+    out = bench_step(rc)
+    sg = torch.sigmoid(out["features"].detach())
+    S = inp["ts"].shape[1]
+    grgb = inp["proj"]["comp_rgb"].reshape(-1, 3).repeat_interleave(S, dim=0)
+    cmax = float((out["weights"].detach() * grgb * 1.002 * sg * (1 - sg)).abs().sum(-1).max())
+    del sg, grgb, out
+    ref = tex_grads(params)
+    head = {"max_cbar": cmax, "exact_ms_per_step": round(timed(lambda: bench_step(rc)), 3)}
+    for frac in (1e-5, 1e-4):
+        rcs = dataclasses.replace(rc, skip_eps_tex=frac * cmax)
+        ms = timed(lambda: bench_step(rcs))
+        stats = torch.zeros((3, 4), dtype=torch.int64, device=device)
+        bench_step(dataclasses.replace(rcs, stats=stats))
+        st = stats.cpu().tolist()[2]
+        head[f"eps_{frac:g}"] = {"ms_per_step": round(ms, 3), "tex_tile_steps_executed_frac": round(st[1] / max(st[0], 1), 4),
+                                 "grad_error": {n: grad_error(g, r) for n, g, r in zip(names, tex_grads(params), ref)}}
+    res["headline"] = head
+    for t in params:
+        t.grad = None
+    if train_step is not None:
+        rdr, run, gp, bound = train_step
+        rdr.grad_skip_eps_tex = 0.0
+        run()
+        tg = lambda: [gp[0].grad[:, 3:].clone()] + [t.grad.clone() for t in gp[4:7]]
+        ref = tg()
+        tr = {"cbar_bound": bound, "exact_ms_per_step": round(timed(run), 3)}
+        for frac in (1e-5, 1e-4):
+            rdr.grad_skip_eps_tex = frac * bound
+            ms = timed(run)
+            run()
+            tr[f"eps_{frac:g}"] = {"ms_per_step": round(ms, 3),
+                                   "grad_error": {n: grad_error(g, r) for n, g, r in zip(names, tg(), ref)}}
+        rdr.grad_skip_eps_tex = 0.0
+        res["patch_renderer_training_shape"] = tr
+    return res
+
+
+def secondary_workloads(device, inp, steps=5, warmup=2, rc=None):
     """(i) configs[1] with the reference's sampler: 128 proposal + 64 importance samples -> 193 intervals per ray
     (proposal decode + tt_sample_importance + render + backward through the plugin);  (ii) the reference TRAINING shape:
     2 prompts x 4 views of 128x128 rays through PatchRenderer (42x42 global + 40x40 patch rays), 193 samples."""
@@ -331,6 +537,7 @@ def secondary_workloads(device, inp, steps=5, warmup=2):
     ro2, rd2 = ro2.to(device), rd2.to(device)
 
     def step2():
+        torch.manual_seed(3)  # the same random patch and jitter every step (the skip comparison needs identical samples)
         out = r2(ro2, rd2, None, bg, **kw2)
         from triplaneturbo_amd import ops
         loss = out["comp_rgb"].mean() + (out["opacity"] ** 2 + 0.01).sqrt().mean() + ops.eikonal_loss(out["sdf_grad"])
@@ -345,6 +552,18 @@ def secondary_workloads(device, inp, steps=5, warmup=2):
                     "rays through PatchRenderer = 42x42 global + 40x40 patch rays per view, 193 samples, planes 256^2, "
                     "fwd+bwd incl. the sampling",
         "ms_per_step": round(ms, 3), "rays_per_step": n_rays, "rays_per_s": round(n_rays / (ms * 1e-3), 1)}
+    if rc is not None:
+        try:
+            res["dense_scene"] = dense_scene(device, inp, rc)
+        except Exception as e:
+            res["dense_scene"] = {"error": repr(e)}
+        try:
+            # |cbar|_1 <= 3 x (d mean / d comp_rgb) x max of 1.002 s (1 - s), weights <= 1
+            bound = 3.0 / (P * NV * 128 * 128 * 3) * 0.2505
+            res["skip"] = skip_workloads(device, inp, rc, (r2.base_renderer, step2, [cache2] + list(geo.parameters()), bound),
+                                         None)
+        except Exception as e:
+            res["skip"] = {"error": repr(e)}
     return res
 
 
@@ -369,8 +588,8 @@ def spawn_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default 300: a ~2.3 s timed region)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=1, choices=(1, 3),
                     help="1 = BASELINE configs[1] per GPU (headline); 3 = configs[3]: 8 prompts x 256x256 rays per GPU")
     ap.add_argument("--exact-f32", action="store_true",
@@ -532,9 +751,30 @@ def main():
                                       "uuid": str(getattr(props, "uuid", ""))})
         ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": info,
                       "distinct_devices": len({(i["uuid"], i["device"]) for i in info})}
+        if backend == "nccl" and ranks_seen["distinct_devices"] < world:
+            # a mis-bound launch (two ranks on one GPU) must not print a scaling point
+            raise SystemExit(f"bench.py: {world} ranks but only {ranks_seen['distinct_devices']} distinct GPUs: {info}")
     ms_per_step = dt / args.steps * 1e3
     n_rays = P * Hh * Ww
     value = n_rays * world * args.steps / dt
+    # a window of at least 2 s of the same step (outside the K timed steps `value` comes from): long enough for a
+    # coarse GPU-activity sampler to see the run, and a check that the K-step number is sustained
+    sustained = None
+    if not args.pmc_child and dt < 2.0 and graph is None:
+        n_more = int(min(5000, max(1, (2.2 - dt) / max(dt / args.steps, 1e-4))))
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_more):
+            step()
+        barrier()
+        dts = time.perf_counter() - t1
+        sustained = {"steps": n_more, "seconds": round(dts, 3), "ms_per_step": round(dts / n_more * 1e3, 4),
+                     "rays_per_s_this_rank": round(n_rays * n_more / dts, 1)}
+
+    # what the kernels executed: device-side counters of ONE more (untimed) step (every rank: the step all-reduces)
+    stats = torch.zeros((3, 4), dtype=torch.int64, device=device)
+    make_step(dataclasses.replace(rc, stats=stats))()
+    torch.cuda.synchronize()
 
     if rank == 0:
         step_ms = sorted(a.elapsed_time(b) for a, b in ev)
@@ -545,14 +785,17 @@ def main():
                 gstep()
             ops.set_kernel_timer(None)
         ksum = timer.summary(median=True)  # label -> (median ms, launches)
-        kernels = {k: dict(kernel_roofline(k, ms, n_samples, args.exact_f32, args.wgrad_f32), launches=n)
+        work = work_fractions(stats, n_samples)
+        kernels = {k: dict(kernel_roofline(k, ms, n_samples, args.exact_f32, args.wgrad_f32, work=work.get(k)), launches=n)
                    for k, (ms, n) in ksum.items() if k in ALG}
         traffic, traffic_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_traffic(args.config)
-        if traffic:
-            for k, v in kernels.items():
-                dk = ALG[k]["device_kernel"]
-                if dk in traffic:
-                    v["pmc"] = dict(traffic[dk], kernel=dk)
+        pipes, pipes_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_pipes(args.config)
+        for k, v in kernels.items():
+            dk = ALG[k]["device_kernel"]
+            if traffic and dk in traffic:
+                v["pmc"] = dict(traffic[dk], kernel=dk)
+            if pipes and dk in pipes:
+                v["sq"] = dict(pipes[dk], kernel=dk)
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         kd = kernels[dom]
         if kd["bound_8d"] == "hbm":
@@ -562,6 +805,13 @@ def main():
                         "unit": "TFLOP/s"}
         roofline.update(
             frac=kd["frac_8d"], definition="frac_8d", frac_pipe_mix=kd["frac_pipe_mix"], avg_kernel_ms=kd["avg_ms"],
+            live_tile_frac=kd.get("live_tile_frac"), inbounds_plane_frac=kd.get("inbounds_plane_frac"),
+            frac_executed=kd.get("frac_8d_executed"), frac_pipe_mix_executed=kd.get("frac_pipe_mix_executed"),
+            mfma_util=(kd.get("sq") or {}).get("mfma_util"), valu_util=(kd.get("sq") or {}).get("valu_util"),
+            waves_per_simd=(kd.get("sq") or {}).get("waves_per_simd"),
+            sq_source=("one rocprofv3 --pmc pass of SQ counters over this script in this run (bench.py: pmc_pipes); "
+                       "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs) is the physical matrix-"
+                       "pipe utilisation north_star's 40 % bar is about") if pipes else f"not collected: {pipes_err}",
             traffic=(kd.get("pmc") or {}).get("bytes"),
             traffic_source=("two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this script in this run: "
                             "(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch of " + ALG[dom]["device_kernel"])
@@ -570,8 +820,10 @@ def main():
                  "TFLOP/s fp32-MFMA) over its median HIP-event duration on the launch stream (entry point = march + "
                  "decode kernels where fused); algorithmic bytes: 3072 B/sample forward reads, 1536 B/sample accumulated "
                  "by each backward kernel (the recompute's re-gather is not algorithmic work); frac_pipe_mix prices each "
-                 "FLOP on the pipe that executes it (split-fp16: 2500/3 TFLOP/s)")
-        hbm = march_roofline(inp, rc, ops, args.steps)
+                 "FLOP on the pipe that executes it (split-fp16: 2500/3 TFLOP/s).  frac counts ALL samples of the launch; "
+                 "frac_executed = the same with the FLOPs x live_tile_frac and the bytes x inbounds_plane_frac the kernel "
+                 "really executed (device counters: tile steps without an in-bounds texel are skipped exactly)")
+        hbm = march_roofline(inp, rc, ops, min(args.steps, 20))
         t_all = sum(v["avg_ms"] for v in kernels.values()) * 1e-3
         stage = {  # whole-step stage rooflines over the time of ALL fused kernels
             "kernel_time_ms": round(t_all * 1e3, 4),
@@ -582,6 +834,11 @@ def main():
                           "frac_of_f32_mfma_peak": round(137088.0 * n_samples / t_all / 1e12 / PEAK_F32_TFLOPS, 4)},
             "glue_ms": round(statistics.median(step_ms) - t_all * 1e3, 4),
         }
+        if all("live_tile_frac" in v for v in kernels.values()) and kernels:
+            ex_flop = sum(v["alg_flop_per_sample"] * v["live_tile_frac"] for v in kernels.values())
+            ex_bytes = sum(v["alg_bytes_per_sample"] * v["inbounds_plane_frac"] for v in kernels.values())
+            stage["sampling_stage"]["executed_frac_of_hbm_peak"] = round(ex_bytes * n_samples / t_all / 1e9 / PEAK_HBM_GBS, 4)
+            stage["mlp_stage"]["executed_frac_of_f32_mfma_peak"] = round(ex_flop * n_samples / t_all / 1e12 / PEAK_F32_TFLOPS, 4)
         cfg_name = {1: "BASELINE configs[1]: per GPU 1 triplane (1,6,32,256,256), 1 view 256x256 rays",
                     3: "BASELINE configs[3]: per GPU 8 prompts (8,6,32,256,256) of a batch sharded over the GPUs, one "
                        "256x256 view each"}[args.config]
@@ -593,8 +850,8 @@ def main():
             "dtype": DTYPE_EXACT if args.exact_f32 else DTYPE,
             "dtype_note": ("TT_R_EXACT_F32: every matrix product on v_mfma_f32_32x32x2_f32" if args.exact_f32 else
                            "fp32 storage, accumulation and element-wise math; every mat-vec product as a 2-term "
-                           "split-fp16 product (v = hi + lo, operands normalised to the top of the fp16 range, 22-bit "
-                           "significands, 3 x v_mfma_f32_32x32x16_f16 into one fp32 accumulator) except the f32 MACs "
+                           "split-fp16 product (v = hi + lo with round-to-nearest-even splits, operands normalised to the top "
+                           "of the fp16 range, ~24-bit significands, 3 x v_mfma_f32_32x32x16_f16 into one fp32 accumulator) except the f32 MACs "
                            "listed in profiles/README.md (weight-gradient outer products, texture scatter GEMM); the "
                            "strict-fp32 number of the same build is `exact_f32` below"),
             "data": "synthetic",
@@ -604,31 +861,33 @@ def main():
                        "loss": float(loss.detach()), "eikonal": "torch ops" if args.torch_loss else "ops.eikonal_loss",
                        "mode": "hipGraph replay" if graph is not None else "eager"},
             "roofline": roofline, "roofline_hbm": hbm, "kernels": kernels, "stages": stage,
+            "timed_region_s": round(dt, 3), "sustained": sustained,
         }
         if world > 1:
             line["multi_gpu"] = {"per_rank_ms_per_step": per_rank_ms, "allreduce_us": allreduce_us,
                                  "allreduce_bytes": bucket.flat_grad.numel() * 4, "rccl": ranks_seen}
         if world == 1 and not args.no_extras and not args.exact_f32:
-            # strict-fp32 sub-result of the same build (driver-visible): 5 steps with TT_R_EXACT_F32
+            # strict-fp32 sub-result of the same build (driver-visible): the SAME number of steps with TT_R_EXACT_F32
             rcx = ops.RenderConfig(exact_f32=True)
             stepx = make_step(rcx)
-            for _ in range(2):
+            for _ in range(3):
                 stepx()
             tx = ops.KernelTimer()
             ops.set_kernel_timer(tx)
+            nx = max(args.steps, 20)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(nx):
                 stepx()
             torch.cuda.synchronize()
-            dtx = (time.perf_counter() - t0) / 5
+            dtx = (time.perf_counter() - t0) / nx
             ops.set_kernel_timer(None)
-            line["exact_f32"] = {"dtype": DTYPE_EXACT, "steps": 5, "ms_per_step": round(dtx * 1e3, 4),
+            line["exact_f32"] = {"dtype": DTYPE_EXACT, "steps": nx, "ms_per_step": round(dtx * 1e3, 4),
                                  "value": round(n_rays / dtx, 1), "unit": "rays/s",
-                                 "kernels": {k: kernel_roofline(k, ms, n_samples, True)
+                                 "kernels": {k: kernel_roofline(k, ms, n_samples, True, work=work.get(k))
                                              for k, (ms, n) in tx.summary(median=True).items() if k in ALG}}
             try:
-                line["secondary"] = secondary_workloads(device, inp)
+                line["secondary"] = secondary_workloads(device, inp, rc=rc)
             except Exception as e:  # the headline must not depend on the extras
                 line["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

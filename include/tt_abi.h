@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 14
+#define TT_ABI_VERSION 15
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -134,6 +134,14 @@ typedef struct {
                                   kernels like LearnedVariance.forward, renderer :34-35): trainable_variance=True
                                   (renderer :53,82; neus_volume_renderer.py:26-37) without a host read-back per step.  Read
                                   by tt_render_fwd / _bwd_geo, tt_march_fwd / _bwd and tt_render_eval */
+    uint64_t* stats;           /* null, or a DEVICE pointer to 4 x uint64 the caller zero-fills: work accounting of the decode
+                                  kernel of tt_render_fwd / tt_decode_rays / tt_render_bwd_geo / tt_render_bwd_tex, added to
+                                  with one atomic per wave: [0] 32-sample tile steps visited, [1] tile steps EXECUTED (those
+                                  that pass the exact skip tests: some texel in bounds -- a tile without one decodes to exact
+                                  zeros --, and in the backward some non-zero upstream gradient), [2] (plane, sample) pairs
+                                  with an in-bounds texel over the gathers that ran (3 planes per sample; the samples a launch
+                                  visits are exactly n_rays * n_samples), [3] reserved.  Measurement only (bench.py:
+                                  live_tile_frac, inbounds_plane_frac) */
 } tt_render_cfg;
 
 #define TT_R_PER_SAMPLE 1 /* also write per-sample sdf / sdf_grad / features (training extras, renderer :532-545) */

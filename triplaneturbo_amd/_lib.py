@@ -105,9 +105,11 @@ def _flag_supported(hipcc: str, pair: List[str]) -> bool:
     if key not in _FLAG_OK:
         with tempfile.TemporaryDirectory(prefix="tt_flag_") as d:
             src = os.path.join(d, "e.hip")
-            open(src, "w").write("__global__ void k() {}\n")
-            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-c", src, "-o", os.path.join(d, "e.o")] + pair,
-                               capture_output=True, text=True)
+            open(src, "w").write("#include <hip/hip_runtime.h>\n__global__ void k() {}\n")
+            base = [hipcc, "--offload-arch=gfx950", "-c", src, "-o", os.path.join(d, "e.o")]
+            if subprocess.run(base, capture_output=True, text=True).returncode != 0:
+                return True  # the probe itself does not compile here: keep the flag and let the real build speak
+            r = subprocess.run(base + pair, capture_output=True, text=True)
         _FLAG_OK[key] = r.returncode == 0
         if r.returncode != 0:
             print(f"triplaneturbo_amd: hipcc rejects '{key}' (performance-only flag): building without it")
@@ -202,7 +204,7 @@ class RenderCfg(ctypes.Structure):
         ("rays_per_view", _I32), ("n_samples", _I32), ("n_rays", _I64), ("radius", _F),
         ("sdf_bias_radius", _F), ("inv_std", _F), ("cos_anneal_ratio", _F), ("rgb_grad_shrink", _F),
         ("flags", _I32), ("image_w", _I32), ("tile_sb", _I32), ("grad_copies", _I32), ("tile_chunk", _I32),
-        ("skip_eps_tex", _F), ("skip_eps_geo", _F), ("inv_std_dev", _P),
+        ("skip_eps_tex", _F), ("skip_eps_geo", _F), ("inv_std_dev", _P), ("stats", _P),
     ]
 
 

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
     const unsigned grad_bytes = (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
 
+    TileStats st = {0, 0, 0};
     f32x16 accW1[2][1] = {{ZERO16}, {ZERO16}};
     f32x16 accW2[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};
     float accw3 = 0.f;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             // that the scalar ALU has just combined (see corners_setup in tt_device.h)
             const float vf = ray_okf * (si < s_end ? 1.f : 0.f);
             const float sbar = in.up[0] * vf, gbx = in.up[1] * vf, gby = in.up[2] * vf, gbz = in.up[3] * vf;
+            st.visited += 1;
             TT_PHASE(0);
             // exact with skip_eps_geo = 0 (the default); > 0: the opt-in approximation of tt_abi.h.  (!(x <= eps): a NaN
             // upstream is never skipped)
@@ -163,9 +165,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             float f[16], u[16];  // u = sbar f + J gbar
             bool anyp[3];
             const bool any = __any(gather_geo_bwd_c(p.packed, (unsigned)(pofs / TT_C), H, W, X, Y, Z, rvalid, sbar, gbx,
-                                                    gby, gbz, ju, jv, lane, Xs, f, u, anyp));
+                                                    gby, gbz, ju, jv, lane, Xs, f, u, anyp, &st.inbounds));
             TT_PHASE(1);
             if (!any) continue;  // exact: no in-bounds texel => f = J = 0, every mask false
+            st.executed += 1;
             float h1[32], h2[32], a2[32], a1[32], q[16];
             mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     flush_wgrad_reduced<64, 32>(L, parity, accW1, p.grads.w1, wave_in_blk, lane, 1.f / sA1, 1.f / sU);
     flush_wgrad_reduced<64, 64>(L, parity, accW2, p.grads.w2, wave_in_blk, lane, 1.f / sA2, 1.f / sV);
     atomicAdd(p.grads.w3 + lane, accw3);
+    tile_stats_flush(cfg.stats, st);
 }
 
 #ifdef TT_TUNING

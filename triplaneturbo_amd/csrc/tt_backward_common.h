@@ -710,6 +710,7 @@ static inline int points_cfg(tt_render_cfg* c, int32_t n_batch, int64_t n_points
     c->sdf_bias_radius = sdf_bias_radius;
     c->inv_std = 1.f;  // unused by the decode kernels
     c->inv_std_dev = nullptr;
+    c->stats = nullptr;
     c->cos_anneal_ratio = 1.f;
     c->rgb_grad_shrink = 1.f;
     c->flags = (q_flags & TT_Q_EXACT_F32) ? TT_R_EXACT_F32 : 0;

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
     const unsigned grad_bytes = (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
 
+    TileStats st = {0, 0, 0};
     f32x16 accV1a[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};  // dV1[:, 0:64]
     f32x16 accV1b[2][1] = {{ZERO16}, {ZERO16}};                  // dV1[:, 64:96]
     f32x16 accV2[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             const float c = shrink * in.wgt * grgb[o] * 1.002f * s * (1.f - s) + in.gf[o];
             cb[o] = c * vf;  // 0/1 factor, not a select on a freshly combined lane mask (see k_decode_bwd_geo)
         }
+        st.visited += 1;
         TT_PHASE(0);
         // exact with skip_eps_tex = 0 (the default: nothing flows back); > 0: the opt-in approximation of tt_abi.h
         if (!__any(!((__builtin_fabsf(cb[0]) + __builtin_fabsf(cb[1])) + __builtin_fabsf(cb[2]) <= cfg.skip_eps_tex)))
@@ -185,9 +187,11 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         sample_position(ox, oy, oz, dx, dy, dz, in.ts, in.te, tm, px, py, pz);
         const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius), Z = scale_coord(pz, cfg.radius);
         float e[48];
-        const bool any = __any(gather_tex_c(p.packed, (unsigned)(pofs / TT_C), H, W, X, Y, Z, valid, lane, Xs, e));
+        const bool any =
+            __any(gather_tex_c(p.packed, (unsigned)(pofs / TT_C), H, W, X, Y, Z, valid, lane, Xs, e, &st.inbounds));
         TT_PHASE(1);
         if (!any) continue;  // exact: e == 0 => k1 = k2 = 0 and every mask is false
+        st.executed += 1;
         // e is needed again only as the Y operand of the dV1 outer product: park it in LDS now ([idx][sample]
         // layout, 96 rows) so its 48 registers are free during the MLP chain.
         // (`region`: always true -- tt_validate_cfg rejects negative flags -- but opaque to the compiler.  The two
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
         for (int o = 0; o < 3; ++o) atomicAdd(p.grads.v3 + o * 64 + 32 * h2 + i, accV3[h2][o]);
+    tile_stats_flush(cfg.stats, st);
 }
 
 static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t s) {

@@ -369,6 +369,23 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
     return any;
 }
 
+// Work accounting (tt_render_cfg.stats): per-wave counters in scalar registers -- the values are wave-uniform (ballots,
+// pop-counts), so counting costs a few SALU instructions per tile step and nothing on the vector pipes.  Flushed with one
+// atomic per counter per wave at kernel end, and only when the caller asked (stats != null).
+struct TileStats {
+    unsigned long long visited;   // tile steps popped and looked at
+    unsigned long long executed;  // tile steps that passed every exact skip test and ran the MLP chain
+    unsigned long long inbounds;  // (plane, sample) pairs with an in-bounds texel, over the gathers that ran
+};
+__device__ __forceinline__ void tile_stats_flush(uint64_t* stats64, const TileStats& s) {
+    unsigned long long* stats = reinterpret_cast<unsigned long long*>(stats64);
+    if (stats && (threadIdx.x & 63) == 0) {
+        atomicAdd(stats + 0, s.visited);
+        atomicAdd(stats + 1, s.executed);
+        atomicAdd(stats + 2, s.inbounds);
+    }
+}
+
 // ---- coalesced gathers ------------------------------------------------------------------------------------------------
 // The gathers above give every lane its own sample: one wave-instruction touches 32 different 128-byte texel lines, 32
 // bytes of each, and a line is fetched by four instructions.  The L1 / texture-address path, not the latency, is what
@@ -425,7 +442,7 @@ template <bool NEED_J>
 __device__ __forceinline__ bool gather_geo_c(const float* __restrict__ planes, unsigned tex0, int H, int W, float X,
                                              float Y, float Z, bool valid, float jscale_u, float jscale_v, int lane,
                                              float* T, float (&f)[16], float (&jx)[16], float (&jy)[16],
-                                             float (&jz)[16]) {
+                                             float (&jz)[16], unsigned long long* inb = nullptr) {
     const int i = lane & 31, hi = lane >> 5, js = lane >> 3, c = lane & 7;
     int* Toff = reinterpret_cast<int*>(T);
     float* Tw = T + 32 * 4;
@@ -441,7 +458,9 @@ __device__ __forceinline__ bool gather_geo_c(const float* __restrict__ planes, u
         Corners cn;
         corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, cn);
         any = any || cn.any;
-        if (!__any(cn.any)) continue;  // exact: every contribution of this plane is 0 for the whole tile
+        const unsigned long long inmask = __ballot(cn.any);
+        if (inb) *inb += (unsigned)__popcll(inmask & 0xffffffffull);
+        if (inmask == 0) continue;  // exact: every contribution of this plane is 0 for the whole tile
         if (hi == 0) {
             const unsigned b = tex0 + (unsigned)(p * HW);
             const ti32x4 o = {(int)(b + cn.off[0]), (int)(b + cn.off[1]), (int)(b + cn.off[2]), (int)(b + cn.off[3])};
@@ -543,7 +562,8 @@ __device__ __forceinline__ bool gather_tex_cp(const float* __restrict__ planes, 
 // `planes` is the base of the packed buffer and `tex0` the texel index of this lane's prompt (a tile may straddle
 // prompts, and the lane that loads a texel is not the lane that owns the sample: the table holds absolute indices).
 __device__ __forceinline__ bool gather_tex_c(const float* __restrict__ planes, unsigned tex0, int H, int W, float X,
-                                             float Y, float Z, bool valid, int lane, float* T, float (&e)[48]) {
+                                             float Y, float Z, bool valid, int lane, float* T, float (&e)[48],
+                                             unsigned long long* inb = nullptr) {
     const int i = lane & 31, hi = lane >> 5, js = lane >> 3, c = lane & 7;
     int* Toff = reinterpret_cast<int*>(T);
     float* Tw = T + 3 * 32 * 4;
@@ -554,7 +574,9 @@ __device__ __forceinline__ bool gather_tex_c(const float* __restrict__ planes, u
     for (int p = 0; p < 3; ++p) {
         Corners cn;
         corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, cn);
-        anyp[p] = __any(cn.any);
+        const unsigned long long inmask = __ballot(cn.any);
+        if (inb) *inb += (unsigned)__popcll(inmask & 0xffffffffull);
+        anyp[p] = inmask != 0;
         any = any || cn.any;
         if (hi == 0) {
             const unsigned b = tex0 + (unsigned)((3 + p) * HW);
@@ -620,7 +642,8 @@ __device__ __forceinline__ void geo_corner_coefs(int p, int H, int W, float X, f
 __device__ __forceinline__ bool gather_geo_bwd_c(const float* __restrict__ planes, unsigned tex0, int H, int W, float X,
                                                  float Y, float Z, bool valid, float sbar, float gux, float guy,
                                                  float guz, float jscale_u, float jscale_v, int lane, float* T,
-                                                 float (&f)[16], float (&u)[16], bool (&anyp)[3]) {
+                                                 float (&f)[16], float (&u)[16], bool (&anyp)[3],
+                                                 unsigned long long* inb = nullptr) {
     const int i = lane & 31, hi = lane >> 5, js = lane >> 3, c = lane & 7;
     int* Toff = reinterpret_cast<int*>(T);
     float* Tw = T + 3 * 32 * 4;
@@ -633,7 +656,9 @@ __device__ __forceinline__ bool gather_geo_bwd_c(const float* __restrict__ plane
         Corners cn;
         float coef[4];
         geo_corner_coefs(p, H, W, X, Y, Z, valid, sbar, gux, guy, guz, jscale_u, jscale_v, cn, coef);
-        anyp[p] = __any(cn.any);
+        const unsigned long long inmask = __ballot(cn.any);
+        if (inb) *inb += (unsigned)__popcll(inmask & 0xffffffffull);
+        anyp[p] = inmask != 0;
         any = any || cn.any;
         if (hi == 0) {
             const unsigned b = tex0 + (unsigned)(p * HW);

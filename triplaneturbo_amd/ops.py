@@ -119,6 +119,10 @@ class RenderConfig:
     # legal under stream capture) and, when it requires grad, render_samples returns d loss / d inv_std through autograd.
     # None = the host float `inv_std` above.
     inv_std_t: Optional[Tensor] = None
+    # measurement hook (tt_render_cfg.stats): a zero-filled CUDA int64 tensor (3, 4); rows = forward / geometry backward /
+    # texture backward decode kernel, columns = tile steps visited, tile steps executed, in-bounds (plane, sample) pairs,
+    # reserved.  bench.py reads `live_tile_frac` from it; None = off
+    stats: Optional[Tensor] = None
 
 
 def planes_pack(space_cache: Tensor) -> Tensor:
@@ -335,7 +339,7 @@ def query_field_grad(space_cache: Tensor, sdf_w: Sequence[Tensor], deform_w: Seq
 
 
 def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, rc: RenderConfig,
-              per_sample: bool, image_w: int = 0) -> "_lib.RenderCfg":
+              per_sample: bool, image_w: int = 0, stats_row: int = 0) -> "_lib.RenderCfg":
     P, _, H, W, _ = packed.shape
     n_views = n_rays // rays_per_view
     if n_views * rays_per_view != n_rays or n_views % P != 0:
@@ -347,13 +351,18 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
         if t.numel() != 1:
             raise ValueError("inv_std_t must hold one float")
         inv_std_dev = t.data_ptr()  # (the tensor is kept alive by `rc`, which the callers hold across the launch)
+    stats = None
+    if rc.stats is not None:
+        if rc.stats.dtype != torch.int64 or not rc.stats.is_cuda or tuple(rc.stats.shape) != (3, 4):
+            raise ValueError("stats must be a CUDA int64 tensor of shape (3, 4)")
+        stats = rc.stats.data_ptr() + 32 * stats_row
     return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
                           inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
                           (_lib.TT_R_PER_SAMPLE if per_sample else 0) | (_lib.TT_R_EXACT_F32 if rc.exact_f32 else 0) |
                           (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0),
                           image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0, int(rc.tile_sb),
                           max(1, int(rc.grad_copies)), max(0, int(rc.tile_chunk)), max(0.0, float(rc.skip_eps_tex)),
-                          max(0.0, float(rc.skip_eps_geo)), inv_std_dev)
+                          max(0.0, float(rc.skip_eps_geo)), inv_std_dev, stats)
 
 
 def render_forward_raw(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], rays_o: Tensor,
@@ -587,7 +596,8 @@ class _TriplaneRenderFn(torch.autograd.Function):
         (packed, w1, w2, w3, v1, v2, v3, rays_o, rays_d, t_starts, t_ends, opacity, depth, trans, weights,
          features, sdf, sdf_grad) = ctx.saved_tensors
         n_rays, S = t_starts.shape
-        cfg = _make_cfg(packed, n_rays, ctx.rays_per_view, S, ctx.rc, True, ctx.image_w)
+        cfg = _make_cfg(packed, n_rays, ctx.rays_per_view, S, ctx.rc, True, ctx.image_w, stats_row=1)
+        cfg_tex = _make_cfg(packed, n_rays, ctx.rays_per_view, S, ctx.rc, True, ctx.image_w, stats_row=2)
         workspace = torch.empty((n_rays * S, 4), device=packed.device, dtype=torch.float32)
         wst, keep = _weights_struct((w1, w2, w3), (v1, v2, v3))
         copies = max(1, int(ctx.rc.grad_copies))
@@ -615,7 +625,7 @@ class _TriplaneRenderFn(torch.autograd.Function):
         with _timed("tt_render_bwd_tex"):
             st = lib.tt_render_bwd_tex(
                 _ptr(packed), ctypes.byref(wst), _ptr(rays_o), _ptr(rays_d), _ptr(t_starts), _ptr(t_ends),
-                ctypes.byref(cfg), _ptr(weights), _ptr(features), _ptr(g_rgb), _ptr(g_features),
+                ctypes.byref(cfg_tex), _ptr(weights), _ptr(features), _ptr(g_rgb), _ptr(g_features),
                 _ptr(grad_packed), ctypes.byref(gst), _stream())
         _lib.check(st, "tt_render_bwd_tex")
         g_packed = None
