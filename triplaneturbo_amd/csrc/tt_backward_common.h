@@ -116,7 +116,12 @@ __device__ __forceinline__ float wg16_scale(float bound) {
 }
 __device__ __forceinline__ unsigned wg16_pack(float x) {  // (hi | lo << 16), both round-to-nearest-even: hi + lo ~ x
     const float hf = (float)cvt_pk16(x, 0.f).x;
-    return cvt_pk16u(x, x - hf);
+#if TT_SPLIT_MODE != 2
+    return cvt_pk16u(x, x - hf);  // (both halves with the same rounding: one packed convert)
+#else
+    const unsigned h = cvt_pk16u(x, 0.f), l = cvt_pk16u_lo(x - hf, 0.f);
+    return (h & 0xffffu) | (l << 16);
+#endif
 }
 template <int N>
 __device__ __forceinline__ void stage_rows16(float* S, const float (&v)[N / 2], int j, int hi, float sc) {
@@ -519,7 +524,7 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
                 for (int j = 0; j < 4; ++j) {
                     const float x0 = bs[ks][2 * j] * bsc, x1 = bs[ks][2 * j + 1] * bsc;
                     const h2_t ph = cvt_pk16(x0, x1);
-                    const h2_t pq = cvt_pk16(x0 - (float)ph.x, x1 - (float)ph.y);
+                    const h2_t pq = cvt_pk16_lo(x0 - (float)ph.x, x1 - (float)ph.y);
                     bh[ks][2 * j] = ph.x;
                     bh[ks][2 * j + 1] = ph.y;
                     bl[ks][2 * j] = pq.x;

@@ -37,16 +37,62 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 // round-toward-zero v_cvt_pkrtz_f16_f32 it replaces since round 4).  With RNE |v - hi| <= 2^-11 |v| and lo = f16(v - hi)
 // is again correctly rounded, so hi + lo carries ~24 significand bits instead of the ~22 of the truncating split
 // (tools/mfma16_probe.hip measures both).  Nothing can overflow: operands are normalised below 2^15 < 65504.
-__device__ __forceinline__ h2_t cvt_pk16(float a, float b) {
+#ifndef TT_SPLIT_MODE
+// dev A/B (tools/build_variants.py), measured on one box, ms per bench step (forward / geometry / texture backward):
+//   1 RTZ (rounds 1-3) 7.77 (1.70 / 2.88 / 2.86)   0 RNE through __builtin_convertvector 8.01 (1.85 / 2.90 / 2.92): hipcc
+//   re-schedules around the fptrunc (+6 spilled registers in k_decode_rays)   4 RNE, the SAME instruction as inline asm
+//   7.81 (1.70 / 2.88 / 2.89), bit-identical results to 0   2 hi RNE / lo RTZ 7.89   3 bias + RTZ 8.23   5 lo only asm 7.85
+#define TT_SPLIT_MODE 4
+#endif
+__device__ __forceinline__ h2_t cvt_pk16_rne(float a, float b) {
     const f2_t v = {a, b};
     return __builtin_convertvector(v, h2_t);
 }
+__device__ __forceinline__ h2_t cvt_pk16_rtz(float a, float b) {
+    return __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+// round to nearest (ties away from zero) on the truncating instruction: half an fp16 ulp (bit 12 of the fp32 pattern)
+// added to the magnitude first
+__device__ __forceinline__ h2_t cvt_pk16_bias(float a, float b) {
+    return cvt_pk16_rtz(__builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) + 0x1000u),
+                        __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) + 0x1000u));
+}
+__device__ __forceinline__ h2_t cvt_pk16_asm(float a, float b) {  // the same instruction, opaque to the optimiser
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return __builtin_bit_cast(h2_t, r);
+}
+// hi term of a split
+__device__ __forceinline__ h2_t cvt_pk16(float a, float b) {
+#if TT_SPLIT_MODE == 4
+    return cvt_pk16_asm(a, b);
+#elif TT_SPLIT_MODE == 1
+    return cvt_pk16_rtz(a, b);
+#elif TT_SPLIT_MODE == 3
+    return cvt_pk16_bias(a, b);
+#else
+    return cvt_pk16_rne(a, b);
+#endif
+}
+// lo term (the residual) of a split
+__device__ __forceinline__ h2_t cvt_pk16_lo(float a, float b) {
+#if TT_SPLIT_MODE == 4 || TT_SPLIT_MODE == 5
+    return cvt_pk16_asm(a, b);
+#elif TT_SPLIT_MODE == 1 || TT_SPLIT_MODE == 2
+    return cvt_pk16_rtz(a, b);
+#elif TT_SPLIT_MODE == 3
+    return cvt_pk16_bias(a, b);
+#else
+    return cvt_pk16_rne(a, b);
+#endif
+}
 __device__ __forceinline__ unsigned cvt_pk16u(float a, float b) { return __builtin_bit_cast(unsigned, cvt_pk16(a, b)); }
+__device__ __forceinline__ unsigned cvt_pk16u_lo(float a, float b) { return __builtin_bit_cast(unsigned, cvt_pk16_lo(a, b)); }
 
 __device__ __forceinline__ void split16(float v, half_t& hi, half_t& lo) {
     const h2_t p = cvt_pk16(v, 0.f);
     hi = p.x;
-    const h2_t q = cvt_pk16(v - (float)hi, 0.f);  // may be subnormal
+    const h2_t q = cvt_pk16_lo(v - (float)hi, 0.f);  // may be subnormal
     lo = q.x;
 }
 
@@ -138,7 +184,7 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
             const f2_t as = SCALED ? ab * sc : ab;  // exact (power of two)
             const h2_t p = cvt_pk16(as.x, as.y);
             const float ra = as.x - (float)p.x, rb = as.y - (float)p.y;  // exact residuals
-            const h2_t q = cvt_pk16(ra, rb);
+            const h2_t q = cvt_pk16_lo(ra, rb);
             bh[2 * j] = p.x;
             bh[2 * j + 1] = p.y;
             bl[2 * j] = q.x;
@@ -186,7 +232,7 @@ __device__ __forceinline__ void split16_vec(const float (&x)[N / 2], float sc, S
         const h2_t p = __builtin_bit_cast(h2_t, pu);
         const float ra = as.x - (float)p.x, rb = as.y - (float)p.y;  // exact residuals
         o.h[t] = pu;
-        o.l[t] = cvt_pk16u(ra, rb);
+        o.l[t] = cvt_pk16u_lo(ra, rb);
     }
 }
 // mv16 on a pre-split operand: y = M x with x = (hi + lo) * un_x
