@@ -25,10 +25,15 @@ RTOL_ELEM = 1e-4
 ATOL_ELEM = 1e-6
 ELEM_SLACK = 1.5    # HIP may violate the element-wise bar vs fp64 on at most 1.5x the fp32 oracle's fraction ...
 ELEM_FLOOR = 5e-3   # ... + 0.5 % of the elements (float-atomic summation order; split-fp16 rounding of tiny elements)
-ELEM_VS_FP32 = 0.08  # and directly against the fp32 oracle at most 8 % of the elements may miss the bar (measured, round 3:
-#                      planes <= 0.1 %, weight matrices <= 5.7 % default path / <= 2.6 % exact-f32 path, worst element
-#                      <= 33x its allowance -- while the fp32 oracle misses the same bar against fp64 on 5 ... 97 % of the
-#                      elements with worst elements 100 ... 18 000x their allowance: profiles/r03_parity_report.jsonl)
+ELEM_VS_FP32 = 0.04  # and directly against the fp32 oracle at most 4 % of the elements may miss the bar: measured in round 4
+#                      (round-to-nearest operand splits, profiles/r04_parity_report.jsonl) planes <= 0.1 %, weight matrices
+#                      <= 3.1 %, worst element <= 5.5x its allowance, + 25 % headroom -- while the fp32 oracle misses the same
+#                      bar against fp64 on 5 ... 97 % of the elements with worst elements 100 ... 18 000x their allowance.
+ELEM_VS_FP32_EXTREME = 0.08  # the one test with weight matrices scaled by 3e5 / 2e-6 / 7e4 (test_weight_matrices_of_any_scale:
+#                      measured 6.3 %, worst element 11x): the fp32 oracle's own intermediate values lose bits there
+NOISE32_CAP = 0.25  # fuzzed, ill-conditioned scenes: the HIP-vs-fp32 bar may widen to at most a quarter of the fp32 oracle's
+#                      own distance from fp64, and only where the exact_f32 kernels on the SAME inputs are as far from the
+#                      fp32 oracle (tests/test_gpu_fuzz.py records both): then it is the scene, not the operand split
 NAMES = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]
 
 
@@ -57,10 +62,12 @@ def report(case, rows):
         pass
 
 
-def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-4, elem=True, noise32=0.0):
+def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-4, elem=True, noise32=0.0,
+                elem_vs_fp32=ELEM_VS_FP32):
     """g_*: lists of tensors (HIP, fp32 oracle, fp64 oracle) in the order of `names`.  noise32 > 0 (fuzzed, possibly
     ill-conditioned scenes only): the direct HIP-vs-fp32 bar is widened to noise32 x the fp32 oracle's own distance from
     fp64 where that is larger -- two fp32 evaluations cannot agree better than either agrees with the exact result."""
+    assert noise32 <= NOISE32_CAP
     rows = {}
     for n, a, b32, b64 in zip(names, g_hip, g32, g64):
         rows[n] = {"hip_vs_fp32": rel(a, b32), "hip_vs_fp64": rel(a, b64), "fp32_vs_fp64": rel(b32, b64),
@@ -73,7 +80,7 @@ def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-
         if elem:
             assert r["elem_hip_vs_fp64"]["viol_frac"] <= ELEM_SLACK * r["elem_fp32_vs_fp64"]["viol_frac"] + ELEM_FLOOR, \
                 (case, n, r)
-            assert r["elem_hip_vs_fp32"]["viol_frac"] <= ELEM_VS_FP32, (case, n, r)
+            assert r["elem_hip_vs_fp32"]["viol_frac"] <= elem_vs_fp32, (case, n, r)
     return rows
 
 

@@ -8,7 +8,7 @@ import torch
 
 from oracle import cpu_ref as O
 
-from parity import check_grads, check_outputs
+from parity import NOISE32_CAP, TOL_VS_FP32, check_grads, check_outputs, rel, report
 from test_gpu_backward import KEYS, _hip_grads, _oracle_grads, mods  # noqa: F401  (fixture)
 
 pytestmark = pytest.mark.gpu
@@ -54,8 +54,23 @@ def test_random_configuration_matches_oracle(mods, seed):
     assert abs(l_hip - l64) <= max(4 * abs(l32 - l64), 1e-5 * abs(l64), 1e-6), (case, l_hip, l32, l64)
     nz = [i for i, t in enumerate(g64) if float(t.abs().max()) > 0]  # (rgb_grad_shrink = 0, S = 1 ...: skip all-zero grads)
     names = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]
+    # A default-path (split-fp16) case further than 1e-4 from the fp32 oracle is run again with the exact_f32 kernels on
+    # the SAME inputs: the wider bar below (<= a quarter of the fp32 oracle's own distance from fp64) is only granted when
+    # the fp32-MFMA path is as far away -- i.e. when the distance is the scene's conditioning, not the operand split.
+    far = [i for i in nz if rel(g_hip[i], g32[i]) > TOL_VS_FP32]
+    noise32 = 0.0
+    if far:
+        noise32 = NOISE32_CAP
+        if not knobs["exact_f32"]:
+            _, _, g_x = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj,
+                                   dict(rck, **dict(knobs, exact_f32=True)))
+            twin = {names[i]: {"default_vs_fp32": rel(g_hip[i], g32[i]), "exact_f32_vs_fp32": rel(g_x[i], g32[i]),
+                               "default_vs_exact_f32": rel(g_hip[i], g_x[i]), "fp32_vs_fp64": rel(g32[i], g64[i])} for i in far}
+            report(case + " [same inputs, exact_f32 twin]", twin)
+            for n, t in twin.items():
+                assert t["exact_f32_vs_fp32"] >= 0.5 * t["default_vs_fp32"], (case, n, t)  # equally far: conditioning
     check_grads(case, [g_hip[i] for i in nz], [g32[i] for i in nz], [g64[i] for i in nz], names=[names[i] for i in nz],
-                elem=False, noise32=0.5)
+                elem=False, noise32=noise32)
     for i in set(range(7)) - set(nz):
         assert float(g_hip[i].abs().max()) == 0.0, (case, names[i])
 
@@ -107,7 +122,7 @@ def test_random_point_query_matches_oracle(seed):
     names = ["points", "planes", "w1", "w2", "w3", "v1", "v2", "v3"]
     nz = [i for i, t in enumerate(g64) if float(t.abs().max()) > 0]
     check_grads(case, [g_hip[i].cpu().reshape(g64[i].shape) for i in nz], [g32[i] for i in nz], [g64[i] for i in nz],
-                names=[names[i] for i in nz], elem=False, noise32=0.5)
+                names=[names[i] for i in nz], elem=False, noise32=NOISE32_CAP)
 
 
 @pytest.mark.parametrize("seed", range(24))
