@@ -34,10 +34,9 @@ struct BwdGeoParams {
 };
 
 #define GEO_SCRATCH_FLOATS (2 * 64 * XS)
-// split-fp16 weight images (tt_mfma16.h): W1, W2 at their fp32 offsets (same bytes), transposes appended
-#define GOFF_W1T LDS_GEO_FLOATS
-#define GOFF_W2T (GOFF_W1T + IMG16_FLOATS(32, 64))
-#define LDS_GEO16_FLOATS (GOFF_W2T + IMG16_FLOATS(64, 64))
+// split-fp16 weight images (tt_mfma16.h): W1, W2 at their fp32 offsets (same bytes); the transposed products read them
+// through ds_read_b64_tr_b16 (mv16t)
+#define LDS_GEO16_FLOATS LDS_GEO_FLOATS
 
 template <bool EXACT, bool WG16>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
@@ -47,8 +46,6 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
         stage_weights<EXACT, 64, 64>(L + OFF_W2, w.w2);
         lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
-        stage_weights_t<EXACT, 64, 32>(L + GOFF_W1T, w.w1);
-        stage_weights_t<EXACT, 64, 64>(L + GOFF_W2T, w.w2);
     }
     const tt_render_cfg& cfg = p.cfg;
     // ---- per-launch operand scales of the fp16 outer products dW1 += a1 u^T, dW2 += a2 v^T (wgrad16 above) ----
@@ -183,20 +180,20 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
             }
             // a2 and a1 feed a product AND an outer product (dW2, dW1): split once under the per-launch scales
-            Split16<64> a2s, a1s;
+            Split16<64, PAIR_TR> a2s, a1s;  // (consumed by the transposed products and the outer-product staging)
             if (WG16) {
-                split16_vec<64>(a2, sA2, a2s);
-                mv16_pre<64, 64>(L + GOFF_W2T, a2s, 1.f / sA2, a1, i, hi);
+                split16_vec<64, PAIR_TR>(a2, sA2, a2s);
+                mv16t_pre<64, 64, 64>(L + OFF_W2, 0, a2s, 1.f / sA2, a1, lane);
             } else {
-                mvtx<EXACT, 64, 64>(L + GOFF_W2T, L + OFF_W2, a2, a1, i, hi);
+                mvtx<EXACT, 64, 64, 64>(L + OFF_W2, 0, a2, a1, i, hi);
             }
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
             if (WG16) {
-                split16_vec<64>(a1, sA1, a1s);
-                mv16_pre<32, 64>(L + GOFF_W1T, a1s, 1.f / sA1, q, i, hi);
+                split16_vec<64, PAIR_TR>(a1, sA1, a1s);
+                mv16t_pre<32, 64, 32>(L + OFF_W1, 0, a1s, 1.f / sA1, q, lane);
             } else {
-                mvtx<EXACT, 32, 64>(L + GOFF_W1T, L + OFF_W1, a1, q, i, hi);
+                mvtx<EXACT, 32, 64, 32>(L + OFF_W1, 0, a1, q, i, hi);
             }
             TT_PHASE(3);
             // ---- network + plane gradients ----

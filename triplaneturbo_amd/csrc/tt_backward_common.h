@@ -136,13 +136,13 @@ __device__ __forceinline__ void stage_rows16_sub(float* S, const float (&v)[TOT]
     for (int r = 0; r < N / 2; ++r) U[LIDX(r, hi) * XS + j] = wg16_pack(v[OFF + r] * sc);
 }
 // the same rows from a vector already split by split16_vec (tt_mfma16.h): one v_perm per staged dword
-template <int N>
-__device__ __forceinline__ void stage_rows16_pre(float* S, const Split16<N>& v, int j, int hi) {
+template <int N, int PAIR>
+__device__ __forceinline__ void stage_rows16_pre(float* S, const Split16<N, PAIR>& v, int j, int hi) {
     unsigned* U = reinterpret_cast<unsigned*>(S);
 #pragma unroll
-    for (int t = 0; t < N / 4; ++t) {
-        U[LIDX(2 * t, hi) * XS + j] = __builtin_amdgcn_perm(v.l[t], v.h[t], 0x05040100u);      // (hi | lo << 16) of 2 t
-        U[LIDX(2 * t + 1, hi) * XS + j] = __builtin_amdgcn_perm(v.l[t], v.h[t], 0x07060302u);  // ... of 2 t + 1
+    for (int t = 0; t < N / 4; ++t) {  // dword t of the split holds registers pair_reg<PAIR>(t, 0 / 1)
+        U[LIDX(pair_reg<PAIR>(t, 0), hi) * XS + j] = __builtin_amdgcn_perm(v.l[t], v.h[t], 0x05040100u);  // (hi | lo << 16)
+        U[LIDX(pair_reg<PAIR>(t, 1), hi) * XS + j] = __builtin_amdgcn_perm(v.l[t], v.h[t], 0x07060302u);
     }
 }
 __device__ __forceinline__ h8_t wg16_frag(const float* S, int row, int t, int hi) {

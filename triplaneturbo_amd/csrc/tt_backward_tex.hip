@@ -30,12 +30,11 @@ struct BwdTexParams {
 #define TV1 0
 #define TV2 (OFF_V2 - OFF_V1)
 #define TV3 (OFF_V3 - OFF_V1)
-// V1, V2 and their transposes as split-fp16 images (tt_mfma16.h): every mat-vec product of the kernel runs on the fp16
-// pipe.  To make room for the V2^T image the per-wave scratch is 128 rows (was 160): the parked e (96 rows) shares it
-// with a 32-row window through which k2 (for dV3) and k1bar (for dV1) are transposed in two halves.
-#define TV1T TEX_W_FLOATS
-#define TV2T (TV1T + IMG16_FLOATS(96, 64))
-#define TEX_W16_FLOATS (TV2T + IMG16_FLOATS(64, 64))
+// V1, V2 as split-fp16 images (tt_mfma16.h): every mat-vec product of the kernel runs on the fp16 pipe; the V2^T / V1^T
+// products read the same images through ds_read_b64_tr_b16 (mv16t; rounds 2-3 kept 43 KB of transposed copies here).
+// The per-wave scratch is 128 rows: the parked e (96 rows) shares it with a 32-row window through which k2 (for dV3)
+// and k1bar (for dV1) are transposed in two halves.
+#define TEX_W16_FLOATS TEX_W_FLOATS
 #define TEX_SCRATCH_FLOATS (128 * XS)
 
 template <bool EXACT, bool WG16>
@@ -46,8 +45,6 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         stage_weights<EXACT, 64, 96>(Lt + TV1, w.v1);
         stage_weights<EXACT, 64, 64>(Lt + TV2, w.v2);
         lds_load_matrix(Lt + TV3, w.v3, 3, 64, 64);
-        stage_weights_t<EXACT, 64, 96>(Lt + TV1T, w.v1);
-        stage_weights_t<EXACT, 64, 64>(Lt + TV2T, w.v2);
     }
     const tt_render_cfg& cfg = p.cfg;
     // ---- per-launch operand scales of the fp16 outer products dV1 += k1bar e^T, dV2 += k2bar k1^T (wgrad16) ----
@@ -267,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         }
         // ---- k1bar = n1 . (V2^T k2bar) ----
         float kb1[32];
-        mvtx<EXACT, 64, 64>(Lt + TV2T, Lt + TV2, k2, kb1, i, hi);
+        mvtx<EXACT, 64, 64, 64>(Lt + TV2, 0, k2, kb1, i, hi);
 #pragma unroll
         for (int r = 0; r < 32; ++r) kb1[r] = k1[r] > 0.f ? kb1[r] : 0.f;
         TT_PHASE(6);
@@ -317,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             scatter_clear<SC_EXACT>(M, lane);
             // ebar = V1^T k1bar for the three planes in ONE product (96 rows: k1bar is split into fp16 terms once)
             float eb[48];
-            mvtx<EXACT, 96, 64, V1S>(Lt + TV1T, Lt + TV1, kb1, eb, i, hi);
+            mvtx<EXACT, 96, 64, 96>(Lt + TV1, 0, kb1, eb, i, hi);
             TT_PHASE(9);
             const int tex0 = (int)(pofs / TT_C);
             scatter_planes<SC_EXACT>(grad_out, grad_bytes, Es, M, tags, Es + 32 * 33, i, hi, [&](int pl, PlaneRefs& refs) {

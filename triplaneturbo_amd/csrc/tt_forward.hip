@@ -140,10 +140,9 @@ struct DecodeCfg {
 };
 
 // outputs are identical in both half-waves.  gq = J^T q (WITHOUT the sphere term).
-// the weight images in L are split-fp16 images (tt_mfma16.h); W1^T / W2^T images at OFF_W1T / OFF_W2T
-#define OFF_W1T LDS_W_FLOATS
-#define OFF_W2T (OFF_W1T + IMG16_FLOATS(32, 64))
-#define LDS_W16_FLOATS (OFF_W2T + IMG16_FLOATS(64, 64))
+// the weight images in L are split-fp16 images (tt_mfma16.h); the W2^T / W1^T products of the normal chain read the SAME
+// images through transposed LDS reads (mv16t) -- rounds 1-3 kept 26 KB of transposed copies here
+#define LDS_W16_FLOATS LDS_W_FLOATS
 
 // texture half: e -> feature net -> c (3 raw features).  Lanes with !valid gather nothing (their c is 0).
 template <bool EXACT>
@@ -211,10 +210,10 @@ __device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& 
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
             }
-            mvtx<EXACT, 64, 64>(L + OFF_W2T, L + OFF_W2, a2, a1, i, hi);
+            mvtx<EXACT, 64, 64, 64>(L + OFF_W2, 0, a2, a1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-            mvtx<EXACT, 32, 64>(L + OFF_W1T, L + OFF_W1, a1, q, i, hi);
+            mvtx<EXACT, 32, 64, 32>(L + OFF_W1, 0, a1, q, i, hi);
             float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -255,16 +254,12 @@ struct QueryParams {
     float* out_feat;
 };
 
-// weight images of the forward decode kernels: split-fp16 (tt_mfma16.h), W1^T / W2^T only when normals are asked for
+// weight images of the forward decode kernels: split-fp16 (tt_mfma16.h)
 template <bool NEED_N, bool NEED_TEX, bool EXACT>
 __device__ __forceinline__ void stage_decode_images(float* L, const MlpPtrs& w) {
     stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
     stage_weights<EXACT, 64, 64>(L + OFF_W2, w.w2);
     lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
-    if (NEED_N) {
-        stage_weights_t<EXACT, 64, 32>(L + OFF_W1T, w.w1);
-        stage_weights_t<EXACT, 64, 64>(L + OFF_W2T, w.w2);
-    }
     if (NEED_TEX) {
         stage_weights<EXACT, 64, 96>(L + OFF_V1, w.v1);
         stage_weights<EXACT, 64, 64>(L + OFF_V2, w.v2);

@@ -218,15 +218,25 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
 // order of mv16, from which the outer product's (hi | lo << 16) dwords are one v_perm each.  Used for vectors whose
 // magnitude does not depend on the sample's upstream gradient (activations, masked weight products): their bound is within
 // a few binades of every sample's own maximum, so the per-launch scale loses nothing against the per-sample one.
-template <int N>
+// Which two registers share a dword of a B fragment.  PAIR_SEQ: dword t <-> registers 2 t, 2 t + 1 (products whose A operand
+// is read row-wise from the image).  PAIR_TR: inside every group of 8 registers (one k-step) the dwords hold registers
+// (0,2) (4,6) (1,3) (5,7): the k-slot order [t0 t2 t4 t6 | t1 t3 t5 t7] in which the TRANSPOSED products receive their A
+// fragments from two ds_read_b64_tr_b16 (mv16t below).
+#define PAIR_SEQ 0
+#define PAIR_TR 1
+template <int PAIR>
+__device__ __forceinline__ constexpr int pair_reg(int t, int which) {
+    return PAIR == PAIR_SEQ ? 2 * t + which : 8 * (t >> 2) + ((t & 3) >> 1) + 4 * (t & 1) + 2 * which;
+}
+template <int N, int PAIR = PAIR_SEQ>
 struct Split16 {
-    unsigned h[N / 4], l[N / 4];  // pair t <-> registers 2 t, 2 t + 1 of the LIDX layout: (f16 hi | f16 hi' << 16), same for lo
+    unsigned h[N / 4], l[N / 4];  // dword t <-> registers pair_reg<PAIR>(t, 0 / 1) of the LIDX layout: (f16 hi | f16 hi' << 16), same for lo
 };
-template <int N>
-__device__ __forceinline__ void split16_vec(const float (&x)[N / 2], float sc, Split16<N>& o) {
+template <int N, int PAIR>
+__device__ __forceinline__ void split16_vec(const float (&x)[N / 2], float sc, Split16<N, PAIR>& o) {
 #pragma unroll
     for (int t = 0; t < N / 4; ++t) {
-        const f2_t ab = {x[2 * t], x[2 * t + 1]};
+        const f2_t ab = {x[pair_reg<PAIR>(t, 0)], x[pair_reg<PAIR>(t, 1)]};
         const f2_t as = ab * sc;  // exact (power of two)
         const unsigned pu = cvt_pk16u(as.x, as.y);
         const h2_t p = __builtin_bit_cast(h2_t, pu);
@@ -237,8 +247,8 @@ __device__ __forceinline__ void split16_vec(const float (&x)[N / 2], float sc, S
 }
 // mv16 on a pre-split operand: y = M x with x = (hi + lo) * un_x
 template <int NOUT, int NIN>
-__device__ __forceinline__ void mv16_pre(const float* img_f, const Split16<NIN>& x, float un_x, float (&y)[NOUT / 2],
-                                         int i, int hi) {
+__device__ __forceinline__ void mv16_pre(const float* img_f, const Split16<NIN, PAIR_SEQ>& x, float un_x,
+                                         float (&y)[NOUT / 2], int i, int hi) {
     constexpr int MT = NOUT / 32, KS = NIN / 16, RS = 2 * NIN + 8;
     const half_t* row = reinterpret_cast<const half_t*>(img_f) + (size_t)i * RS + 8 * hi;
     const float un = img_f[(size_t)i * (NIN + 4) + NIN] * un_x;
@@ -271,6 +281,130 @@ __device__ __forceinline__ void mv16_pre(const float* img_f, const Split16<NIN>&
         for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k] * un;
 }
 
+// ---- TRANSPOSED products from the forward image: y = M^T x without a second (transposed) image ----------------------------
+// gfx950's LDS transpose read, ds_read_b64_tr_b16: inside every group of 16 lanes, output lane i, element j = half (i % 4)
+// of the 8-byte chunk addressed by lane 4 j + i / 4 (tools/ds_tr_probe.hip).  The forward image of M (rows R = the
+// contraction index of M^T x, row length KM) stores every aligned group of four consecutive columns as four contiguous
+// halfs, so a lane group pointed at rows {R0, R0 + 2, R0 + 8, R0 + 10} receives, per lane = column c, the four k-slots
+// t = 0, 2, 4, 6 of an MFMA A fragment of M^T, and a second read one row further down the slots t = 1, 3, 5, 7.  With that
+// choice of rows (and the images' row stride of K + 4 floats = 4 banks mod 64) the 32 lanes of a read cycle touch all 64
+// banks exactly once: conflict-free.  The B operand pairs its registers accordingly (PAIR_TR).  Rounds 1-3 kept a second,
+// transposed image of W1, W2 (26 KB) and of V1, V2 (43 KB) per workgroup for these products.
+typedef short sv4_t __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) sv4_t lds_sv4_t;
+
+// per-lane base of the transposed fragments of the NOUT columns that start at column col0 (a multiple of 16)
+template <int KM>
+__device__ __forceinline__ const lds_sv4_t* tr_lane_base(const float* img_f, int col0, int lane) {
+    constexpr int RS = 2 * KM + 8;
+    const int L = lane & 15, g1 = (lane >> 4) & 1, hh = lane >> 5, j = L >> 2, q = L & 3;
+    const int r1 = 2 * (j & 1) + 8 * (j >> 1) + 4 * hh;
+    const int off = r1 * RS + 32 * ((col0 >> 4) + g1) + 8 * (q & 1) + 4 * (q >> 1);  // halfs; a multiple of 4
+    return (const lds_sv4_t*)(reinterpret_cast<const half_t*>(img_f) + off);
+}
+// A fragment of M^T: k-step ks (16 rows of M), column tile m (32 columns), term 0 (hi) / 1 (lo)
+template <int KM>
+__device__ __forceinline__ h8_t tr_frag(const lds_sv4_t* base, int ks, int m, int term) {
+    constexpr int RS = 2 * KM + 8;
+    const int off4 = (16 * ks * RS + 64 * m + 16 * term) / 4;  // in 8-byte units (compile-time constant after unrolling)
+    const sv4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_sv4_t*>(base) + off4);
+    const sv4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_sv4_t*>(base) + off4 + RS / 4);
+    typedef short sv8_t __attribute__((__vector_size__(8 * sizeof(short))));
+    const sv8_t ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(h8_t, ab);
+}
+
+// y[NOUT] = M[NIN][col0 .. col0 + NOUT)^T x[NIN]; img_f = forward image of M (NIN rows, KM columns)
+template <int NOUT, int NIN, int KM, bool SCALED = true>
+__device__ __forceinline__ void mv16t(const float* img_f, int col0, const float (&x)[NIN / 2], float (&y)[NOUT / 2],
+                                      int lane) {
+    constexpr int MT = NOUT / 32, KS = NIN / 16;
+    const lds_sv4_t* base = tr_lane_base<KM>(img_f, col0, lane);
+    const float wun = img_f[KM];  // inverse of the matrix normalisation (the same in the pad of every row)
+    float sc = 1.f, un = wun;
+    if (SCALED) {
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < NIN / 2; ++r) m = fmaxf(m, __builtin_fabsf(x[r]));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        int E = (int)(__builtin_bit_cast(unsigned, m) >> 23);
+        E = E < 16 ? 16 : (E > 240 ? 240 : E);
+        sc = __builtin_bit_cast(float, (unsigned)(268 - E) << 23);
+        un = wun * __builtin_bit_cast(float, (unsigned)(E - 14) << 23);
+    }
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        acc[m] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (TT_MV16_FENCE) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        h8_t bh, bl;  // k-slot order [t0 t2 t4 t6 | t1 t3 t5 t7]
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const f2_t ab = {x[8 * s + pair_reg<PAIR_TR>(d, 0)], x[8 * s + pair_reg<PAIR_TR>(d, 1)]};
+            const f2_t as = SCALED ? ab * sc : ab;
+            const h2_t p = cvt_pk16(as.x, as.y);
+            const float ra = as.x - (float)p.x, rb = as.y - (float)p.y;
+            const h2_t q = cvt_pk16_lo(ra, rb);
+            bh[2 * d] = p.x;
+            bh[2 * d + 1] = p.y;
+            bl[2 * d] = q.x;
+            bl[2 * d + 1] = q.y;
+        }
+        h8_t ah[MT], al[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ah[m] = tr_frag<KM>(base, s, m, 0);
+            al[m] = tr_frag<KM>(base, s, m, 1);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k] * un;
+}
+// the same on an operand already split in PAIR_TR order (x = (hi + lo) * un_x)
+template <int NOUT, int NIN, int KM>
+__device__ __forceinline__ void mv16t_pre(const float* img_f, int col0, const Split16<NIN, PAIR_TR>& x, float un_x,
+                                          float (&y)[NOUT / 2], int lane) {
+    constexpr int MT = NOUT / 32, KS = NIN / 16;
+    const lds_sv4_t* base = tr_lane_base<KM>(img_f, col0, lane);
+    const float un = img_f[KM] * un_x;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        acc[m] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const h8_t bh = __builtin_bit_cast(h8_t, u4_t{x.h[4 * s], x.h[4 * s + 1], x.h[4 * s + 2], x.h[4 * s + 3]});
+        const h8_t bl = __builtin_bit_cast(h8_t, u4_t{x.l[4 * s], x.l[4 * s + 1], x.l[4 * s + 2], x.l[4 * s + 3]});
+        h8_t ah[MT], al[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ah[m] = tr_frag<KM>(base, s, m, 0);
+            al[m] = tr_frag<KM>(base, s, m, 1);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k] * un;
+}
+
 // ---- precision switch ----------------------------------------------------------------------------------------------
 // EXACT = true (cfg.flags & TT_R_EXACT_F32): every matrix product on v_mfma_f32_32x32x2_f32 (bit-for-bit a k-ordered
 // fmaf chain, 1/16 of the fp16 pipe's rate) from plain fp32 weight images -- the A/B reference for the split-fp16
@@ -284,11 +418,6 @@ __device__ __forceinline__ void stage_weights(float* dst_f, const float* __restr
         stage_image16<ROWS, K, false>(dst_f, src, K);
     }
 }
-// image of src^T for the `M^T x` products (src is ROWS_SRC x K_SRC row-major); nothing to do when EXACT
-template <bool EXACT, int ROWS_SRC, int K_SRC>
-__device__ __forceinline__ void stage_weights_t(float* dst_f, const float* __restrict__ src) {
-    if constexpr (!EXACT) stage_image16<K_SRC, ROWS_SRC, true>(dst_f, src, K_SRC);
-}
 
 // y[NOUT] = M[NOUT][NIN] x
 template <bool EXACT, int NOUT, int NIN>
@@ -299,14 +428,14 @@ __device__ __forceinline__ void mvx(const float* img, const float (&x)[NIN / 2],
         mv16<NOUT, NIN>(img, x, y, i, hi);
     }
 }
-// y[NOUT] = M^T x for M stored [NIN][STRIDE - 4 columns]: `img_t` is the split-fp16 image of the transposed (slice of)
-// M, `img` the fp32 image of M itself, already offset to the first of the NOUT columns.
-template <bool EXACT, int NOUT, int NIN, int STRIDE = NOUT + 4>
-__device__ __forceinline__ void mvtx(const float* img_t, const float* img, const float (&x)[NIN / 2],
-                                     float (&y)[NOUT / 2], int i, int hi) {
+// y[NOUT] = M[:, col0 .. col0 + NOUT)^T x for M (NIN rows, KM columns) staged by stage_weights at `img`: from the fp32
+// image by strided column reads (EXACT), from the split-fp16 image by transposed reads (mv16t)
+template <bool EXACT, int NOUT, int NIN, int KM>
+__device__ __forceinline__ void mvtx(const float* img, int col0, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i,
+                                     int hi) {
     if constexpr (EXACT) {
-        mv_bwd<NOUT, NIN, STRIDE>(img, x, y, i, hi);
+        mv_bwd<NOUT, NIN, KM + 4>(img + col0, x, y, i, hi);
     } else {
-        mv16<NOUT, NIN>(img_t, x, y, i, hi);
+        mv16t<NOUT, NIN, KM>(img, col0, x, y, 32 * hi + i);
     }
 }

@@ -19,14 +19,10 @@
 #define PX_W1 0
 #define PX_W2 (PX_W1 + IMG16_FLOATS(64, 32))
 #define PX_W3 (PX_W2 + IMG16_FLOATS(64, 64))
-#define PX_W1T (PX_W3 + 64)
-#define PX_W2T (PX_W1T + IMG16_FLOATS(32, 64))
-#define PX_V1 (PX_W2T + IMG16_FLOATS(64, 64))
+#define PX_V1 (PX_W3 + 64)
 #define PX_V2 (PX_V1 + IMG16_FLOATS(64, 96))
 #define PX_V3 (PX_V2 + IMG16_FLOATS(64, 64))
-#define PX_V1T (PX_V3 + 3 * 64)
-#define PX_V2T (PX_V1T + IMG16_FLOATS(96, 64))
-#define PX_FLOATS (PX_V2T + IMG16_FLOATS(64, 64))
+#define PX_FLOATS (PX_V3 + 3 * 64) /* (the transposed products read the same images: mv16t) */
 
 struct PointsBwdXParams {
     const float* packed;
@@ -61,14 +57,10 @@ __global__ __launch_bounds__(256, 1) void k_points_bwd_x(PointsBwdXParams p) {
         stage_weights<EXACT, 64, 32>(L + PX_W1, w.w1);
         stage_weights<EXACT, 64, 64>(L + PX_W2, w.w2);
         lds_load_matrix(L + PX_W3, w.w3, 1, 64, 64);
-        stage_weights_t<EXACT, 64, 32>(L + PX_W1T, w.w1);
-        stage_weights_t<EXACT, 64, 64>(L + PX_W2T, w.w2);
         if (p.g_feat) {  // (block-uniform: the staging helpers synchronise)
             stage_weights<EXACT, 64, 96>(L + PX_V1, w.v1);
             stage_weights<EXACT, 64, 64>(L + PX_V2, w.v2);
             lds_load_matrix(L + PX_V3, w.v3, 3, 64, 64);
-            stage_weights_t<EXACT, 64, 96>(L + PX_V1T, w.v1);
-            stage_weights_t<EXACT, 64, 64>(L + PX_V2T, w.v2);
         }
     }
     __syncthreads();
@@ -120,10 +112,10 @@ __global__ __launch_bounds__(256, 1) void k_points_bwd_x(PointsBwdXParams p) {
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
                 }
-                mvtx<EXACT, 64, 64>(L + PX_W2T, L + PX_W2, a2, a1, i, hi);
+                mvtx<EXACT, 64, 64, 64>(L + PX_W2, 0, a2, a1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-                mvtx<EXACT, 32, 64>(L + PX_W1T, L + PX_W1, a1, q, i, hi);
+                mvtx<EXACT, 32, 64, 32>(L + PX_W1, 0, a1, q, i, hi);
             }
         }
         if (need_tex) {
@@ -146,14 +138,13 @@ __global__ __launch_bounds__(256, 1) void k_points_bwd_x(PointsBwdXParams p) {
                         k2[4 * g + e2] = k2[4 * g + e2] > 0.f ? t : 0.f;
                     }
                 }
-                mvtx<EXACT, 64, 64>(L + PX_V2T, L + PX_V2, k2, kb1, i, hi);
+                mvtx<EXACT, 64, 64, 64>(L + PX_V2, 0, k2, kb1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) kb1[r] = k1[r] > 0.f ? kb1[r] : 0.f;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {  // ebar_p = (V1[:, 32p : 32p+32])^T k1bar
                     float ebp[16];
-                    mvtx<EXACT, 32, 64, V1S>(L + PX_V1T + (size_t)32 * pl * (64 + 4), L + PX_V1 + 32 * pl, kb1, ebp, i,
-                                             hi);
+                    mvtx<EXACT, 32, 64, 96>(L + PX_V1, 32 * pl, kb1, ebp, i, hi);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) eb[16 * pl + r] = ebp[r];
                 }
