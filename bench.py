@@ -596,6 +596,8 @@ def main():
                     help="A/B: every matrix product on the fp32-input MFMA (TT_R_EXACT_F32) instead of split-fp16")
     ap.add_argument("--wgrad-f32", action="store_true",
                     help="A/B: weight-gradient outer products on the fp32 MFMA (TT_R_WGRAD_F32) instead of split-fp16")
+    ap.add_argument("--bwd-pair", action="store_true",
+                    help="A/B: the wave-pair texture backward kernel (TT_R_BWD_PAIR) instead of one wave per tile")
     ap.add_argument("--torch-loss", action="store_true",
                     help="A/B: the eikonal term of the G6 loss with plain torch ops instead of ops.eikonal_loss")
     ap.add_argument("--graph", action="store_true",
@@ -649,7 +651,7 @@ def main():
     R, Hh, Ww, S = 256, 256, 256, 128
     inp = make_inputs(rank, world, device, args.config, R, Hh, Ww, S)
     P = inp["cache"].shape[0]
-    rc = ops.RenderConfig(exact_f32=args.exact_f32, wgrad_f32=args.wgrad_f32, tile_sb=args.tile_sb,
+    rc = ops.RenderConfig(exact_f32=args.exact_f32, wgrad_f32=args.wgrad_f32, bwd_pair=args.bwd_pair, tile_sb=args.tile_sb,
                           tile_chunk=args.tile_chunk, grad_copies=args.grad_copies)
     bucket = FlatGradBucket(inp["sw"] + inp["fw"])  # MLP grads = views of one buffer: one collective, no cat / copies
     fused = not args.torch_loss

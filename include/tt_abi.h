@@ -152,6 +152,11 @@ typedef struct {
 #define TT_R_WGRAD_F32 4  /* backward: weight-gradient outer products on the fp32-input MFMA (implied by TT_R_EXACT_F32)
                              instead of the default split-fp16 products with per-launch operand scales; A/B switch */
 
+#define TT_R_BWD_SOLO 8   /* backward: force the one-wave-per-tile decode kernels (the default) */
+#define TT_R_BWD_PAIR 16  /* backward: the wave-pair texture kernel (two waves share a 32-sample tile and split every hidden
+                             layer and the weight-gradient accumulators: 256 registers, two waves per SIMD); A/B switch,
+                             default precision only, bit-for-bit the same arithmetic up to summation order */
+
 /* tt_query_points / tt_query_field / tt_decode_rays / tt_points_bwd_* flags */
 #define TT_Q_NORMAL 1    /* output sdf_grad (analytic normal path) */
 #define TT_Q_TEX 2       /* output features (texture planes + feature net) */

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libtt_hip.so")
 # dev-only variant built with -DTT_TUNING: honours the TT_DEBUG_FLAGS / TT_SB / TT_CHUNK / TT_UNIT / TT_ORDER
 # environment variables (profiling ablations and tuning sweeps, tools/).  The product library above never calls getenv.
 TUNING_LIB_PATH = os.path.join(_HERE, "libtt_hip_tuning.so")
-SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_backward_tex.hip", "tt_points.hip", "tt_composite.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
+SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_backward_tex.hip", "tt_backward_tex2.hip", "tt_points.hip", "tt_composite.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
 # per-translation-unit flags: the texture backward is faster under hipcc's max-ILP scheduling strategy (3.11 -> 3.02 ms;
 # the other kernels are not); the geometry backward is faster with its transient MFMA results in VGPRs rather than AGPRs
 # (-amdgpu-mfma-vgpr-form: 471 -> 248 v_accvgpr_read, 3.045 -> 2.995 ms; texture backward slower, forward neutral) and
@@ -216,6 +216,8 @@ class HashGridCfg(ctypes.Structure):  # tt_hashgrid_cfg
 TT_R_PER_SAMPLE = 1
 TT_R_EXACT_F32 = 2
 TT_R_WGRAD_F32 = 4
+TT_R_BWD_SOLO = 8
+TT_R_BWD_PAIR = 16
 TT_Q_NORMAL = 1
 TT_Q_TEX = 2
 TT_Q_EXACT_F32 = 4

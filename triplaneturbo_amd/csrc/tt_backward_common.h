@@ -579,6 +579,39 @@ struct MlpGradPtrs {
     float* v3;
 };
 
+// ---- texture half: parameters and weight-image map shared by tt_backward_tex.hip and tt_backward_tex2.hip ----
+struct BwdTexParams {
+    const float* packed;
+    MlpPtrs w;
+    const float* rays_o;
+    const float* rays_d;
+    const float* t_starts;
+    const float* t_ends;
+    tt_render_cfg cfg;
+    const float* weights;
+    const float* features;
+    const float* g_rgb;
+    const float* g_features;
+    TileGeom geom;
+    long long n_items;
+    int* queue;  // per-XCD item counters (tt_queue_counters)
+    int n_copies;
+    float* grad_packed;
+    MlpGradPtrs grads;
+    unsigned long long* phase_cycles;  // tuning build only (TT_PHASE), else null
+};
+
+#define TEX_W_FLOATS (LDS_W_FLOATS - OFF_V1)
+#define TV1 0
+#define TV2 (OFF_V2 - OFF_V1)
+#define TV3 (OFF_V3 - OFF_V1)
+// V1, V2 as split-fp16 images (tt_mfma16.h): every mat-vec product of the kernel runs on the fp16 pipe; the V2^T / V1^T
+// products read the same images through ds_read_b64_tr_b16 (mv16t; rounds 2-3 kept 43 KB of transposed copies here).
+// The per-wave scratch is 128 rows: the parked e (96 rows) shares it with a 32-row window through which k2 (for dV3)
+// and k1bar (for dV1) are transposed in two halves.
+#define TEX_W16_FLOATS TEX_W_FLOATS
+void tt_launch_bwd_tex2(const BwdTexParams& p, int cus, hipStream_t s);  // tt_backward_tex2.hip
+
 // =====================================================================================================
 // host side
 // =====================================================================================================

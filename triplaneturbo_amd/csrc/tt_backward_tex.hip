@@ -5,36 +5,6 @@
 // =====================================================================================================
 // texture half
 // =====================================================================================================
-struct BwdTexParams {
-    const float* packed;
-    MlpPtrs w;
-    const float* rays_o;
-    const float* rays_d;
-    const float* t_starts;
-    const float* t_ends;
-    tt_render_cfg cfg;
-    const float* weights;
-    const float* features;
-    const float* g_rgb;
-    const float* g_features;
-    TileGeom geom;
-    long long n_items;
-    int* queue;  // per-XCD item counters (tt_queue_counters)
-    int n_copies;
-    float* grad_packed;
-    MlpGradPtrs grads;
-    unsigned long long* phase_cycles;  // tuning build only (TT_PHASE), else null
-};
-
-#define TEX_W_FLOATS (LDS_W_FLOATS - OFF_V1)
-#define TV1 0
-#define TV2 (OFF_V2 - OFF_V1)
-#define TV3 (OFF_V3 - OFF_V1)
-// V1, V2 as split-fp16 images (tt_mfma16.h): every mat-vec product of the kernel runs on the fp16 pipe; the V2^T / V1^T
-// products read the same images through ds_read_b64_tr_b16 (mv16t; rounds 2-3 kept 43 KB of transposed copies here).
-// The per-wave scratch is 128 rows: the parked e (96 rows) shares it with a 32-row window through which k2 (for dV3)
-// and k1bar (for dV1) are transposed in two halves.
-#define TEX_W16_FLOATS TEX_W_FLOATS
 #define TEX_SCRATCH_FLOATS (128 * XS)
 
 template <bool EXACT, bool WG16>
@@ -388,7 +358,13 @@ static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t
             const long long n = p.cfg.n_rays * p.cfg.n_samples * 3;
             hipLaunchKernelGGL(k_absmax1, dim3(absmax_blocks(n)), dim3(256), 0, s, p.g_features, n, bnd + TT_BOUND_UP1);
         }
-        hipLaunchKernelGGL((k_decode_bwd_tex<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        // render path, default precision: the wave-pair kernel (tt_backward_tex2.hip: two waves per SIMD) when the caller asks
+        // for it (TT_R_BWD_PAIR: opt-in while it is slower than the one-wave-per-tile kernel); the
+        // per-point variant (no march weights) always runs the latter
+        if (p.weights && (p.cfg.flags & TT_R_BWD_PAIR) && !(p.cfg.flags & TT_R_BWD_SOLO))
+            tt_launch_bwd_tex2(p, tt_num_cus(), s);
+        else
+            hipLaunchKernelGGL((k_decode_bwd_tex<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     } else if (p.cfg.flags & TT_R_EXACT_F32) {
         hipLaunchKernelGGL((k_decode_bwd_tex<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     } else {

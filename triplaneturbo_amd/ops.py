@@ -110,6 +110,7 @@ class RenderConfig:
     tile_chunk: int = 0  # samples of a ray block per work item (performance knob); 0 = automatic
     exact_f32: bool = False  # TT_R_EXACT_F32: all matrix products on the fp32-input MFMA (A/B reference, ~1.6x slower)
     wgrad_f32: bool = False  # TT_R_WGRAD_F32: weight-gradient outer products on the fp32 MFMA (A/B of the fp16 ones)
+    bwd_pair: bool = False  # TT_R_BWD_PAIR: the wave-pair texture backward kernel (A/B switch; default: one wave per tile)
     # OPT-IN approximation of the backward (0 = exact): skip 32-sample tiles whose upstream gradients are all below the
     # threshold (tt_render_cfg.skip_eps_tex / skip_eps_geo in include/tt_abi.h; error measured in tests/test_gpu_skip.py)
     skip_eps_tex: float = 0.0
@@ -359,7 +360,7 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
     return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
                           inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
                           (_lib.TT_R_PER_SAMPLE if per_sample else 0) | (_lib.TT_R_EXACT_F32 if rc.exact_f32 else 0) |
-                          (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0),
+                          (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0) | (_lib.TT_R_BWD_PAIR if rc.bwd_pair else 0),
                           image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0, int(rc.tile_sb),
                           max(1, int(rc.grad_copies)), max(0, int(rc.tile_chunk)), max(0.0, float(rc.skip_eps_tex)),
                           max(0.0, float(rc.skip_eps_geo)), inv_std_dev, stats)
