@@ -762,7 +762,7 @@ def main():
     # a window of at least 2 s of the same step (outside the K timed steps `value` comes from): long enough for a
     # coarse GPU-activity sampler to see the run, and a check that the K-step number is sustained
     sustained = None
-    if not args.pmc_child and dt < 2.0 and graph is None:
+    if not args.pmc_child and not args.no_extras and dt < 2.0 and graph is None:
         n_more = int(min(5000, max(1, (2.2 - dt) / max(dt / args.steps, 1e-4))))
         barrier()
         t1 = time.perf_counter()
