@@ -198,6 +198,102 @@ __device__ __forceinline__ void wgrad16_row(f32x16 (&acc)[NY / 32], const float*
     }
 }
 
+// ---- fragment images: activation vectors in LDS as ready-made split-fp16 MFMA fragments -------------------------------
+// A 16 n-element vector of the tile's 32 samples is stored as blocks [k-step][half-wave] of 32 rows (samples) x 8 halfs =
+// the B fragment of that sample for that k-step: one ds_write_b128 per lane and k-step straight from a Split16 (a hi image
+// and a lo image), instead of one ds_write_b32 per element into the [index][sample] scratch of rounds 2-3.  A block is
+// padded to FR_BLK halfs so that the TRANSPOSED reads below hit all 64 banks (block stride = 16 dwords mod 64, k-step
+// stride = 32).
+#define FR_BLK 288
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+// fragments of one k-step: (hi, lo) 8 halfs each
+struct Frag {
+    h8_t h, l;
+};
+__device__ __forceinline__ Frag frag_lds(const half_t* img_h, const half_t* img_l, int ks, int hi, int j) {
+    Frag f;
+    f.h = *reinterpret_cast<const h8_t*>(img_h + (ks * 2 + hi) * FR_BLK + j * 8);
+    f.l = *reinterpret_cast<const h8_t*>(img_l + (ks * 2 + hi) * FR_BLK + j * 8);
+    return f;
+}
+__device__ __forceinline__ void frag_store(half_t* img_h, half_t* img_l, int ks, int hi, int j, const Frag& f) {
+    *reinterpret_cast<h8_t*>(img_h + (ks * 2 + hi) * FR_BLK + j * 8) = f.h;
+    *reinterpret_cast<h8_t*>(img_l + (ks * 2 + hi) * FR_BLK + j * 8) = f.l;
+}
+// all k-steps of a split vector (this lane: sample i, half-wave hi)
+template <int N, int PAIR>
+__device__ __forceinline__ void frag_image_store(half_t* img_h, half_t* img_l, const Split16<N, PAIR>& v, int i, int hi) {
+#pragma unroll
+    for (int s = 0; s < N / 16; ++s) {
+        *reinterpret_cast<u4_t*>(img_h + (s * 2 + hi) * FR_BLK + i * 8) = u4_t{v.h[4 * s], v.h[4 * s + 1], v.h[4 * s + 2], v.h[4 * s + 3]};
+        *reinterpret_cast<u4_t*>(img_l + (s * 2 + hi) * FR_BLK + i * 8) = u4_t{v.l[4 * s], v.l[4 * s + 1], v.l[4 * s + 2], v.l[4 * s + 3]};
+    }
+}
+// ---- outer-product operands straight from the fragment images: transposed LDS reads ----
+// An outer product over the samples wants, per lane = matrix row (or column), the 32 samples as k-slots; the images hold,
+// per sample, 8 elements as k-slots.  ds_read_b64_tr_b16 turns one into the other: a 16-lane group whose lane 4 j + q
+// points at the 8-byte piece q (half-wave block q & 1, upper / lower four slots q >> 1) of sample s0 + j receives, in lane
+// 4 q + e, slot e of that piece for the four samples j = 0..3.  Four reads cover this half-wave's 16 samples
+// (register 4 n + j <-> sample 16 hh' + 4 n + j); the hi and the lo image are read alike and zipped into (hi | lo << 16).
+// Which ELEMENT of the 32-element block a lane ends up with depends on the slot order of the image: identity for
+// PAIR_SEQ images, tr_elem() for PAIR_TR ones -- a permutation of the rows of the accumulated matrix, undone at the flush.
+__device__ __forceinline__ int tr_elem(int x) {  // lane x (0..31) of a PAIR_TR operand holds this element of the block
+    const int q = (x >> 2) & 3, e = x & 3;
+    return 16 * (x >> 4) + 2 * (e & 1) + 8 * (e >> 1) + (q >> 1) + 4 * (q & 1);
+}
+// ORDER 0: register 4 n + j <-> sample 16 hh' + 4 n + j (both operands of a product built this way).  ORDER 1: register
+// 4 n + j <-> sample 8 n + 4 hh' + j, the k-slot order of wg16_frag -- for products whose other operand comes from the
+// [index][sample] scratch.
+template <int ORDER = 0>
+__device__ __forceinline__ void tr_operand(const half_t* img_h, const half_t* img_l, int blk, int lane, unsigned (&T)[16]) {
+    const int L = lane & 15, gg = lane >> 4, j = L >> 2, q = L & 3;
+    const int row0 = ORDER == 0 ? 16 * (gg >> 1) + j : 4 * (gg >> 1) + j;  // the read n adds 4 n / 8 n rows
+    const int off = ((2 * blk + (gg & 1)) * 2 + (q & 1)) * FR_BLK + row0 * 8 + 4 * (q >> 1);  // halfs
+    const lds_sv4_t* ph = (const lds_sv4_t*)(img_h + off);
+    const lds_sv4_t* pl = (const lds_sv4_t*)(img_l + off);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {  // four more samples per read: + 4 rows of 16 bytes
+        const sv4_t h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_sv4_t*>(ph) + (ORDER == 0 ? 8 : 16) * n);
+        const sv4_t l4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_sv4_t*>(pl) + (ORDER == 0 ? 8 : 16) * n);
+        const u2_t hu = __builtin_bit_cast(u2_t, h4), lu = __builtin_bit_cast(u2_t, l4);
+        T[4 * n + 0] = __builtin_amdgcn_perm(lu[0], hu[0], 0x05040100u);
+        T[4 * n + 1] = __builtin_amdgcn_perm(lu[0], hu[0], 0x07060302u);
+        T[4 * n + 2] = __builtin_amdgcn_perm(lu[1], hu[1], 0x05040100u);
+        T[4 * n + 3] = __builtin_amdgcn_perm(lu[1], hu[1], 0x07060302u);
+    }
+}
+// acc += X Y^T over the 32 samples (X, Y: tr_operand outputs)
+__device__ __forceinline__ void outer16(f32x16& acc, const unsigned (&X)[16], const unsigned (&Y)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const h8_t xa = __builtin_bit_cast(h8_t, u4_t{X[4 * g], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]});
+        const h8_t yb = __builtin_bit_cast(h8_t, u4_t{Y[4 * g], Y[4 * g + 1], Y[4 * g + 2], Y[4 * g + 3]});
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, yb, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, wg16_swap(yb), acc, 0, 0, 0);
+    }
+}
+
+
+// acc[n] += X Y_n^T: X = a tr_operand<1> (32 rows = lanes), Y_n = rows 32 n .. of the [index][sample] scratch (wg16_frag)
+template <int NY>
+__device__ __forceinline__ void wgrad16_xt(f32x16 (&acc)[NY], const unsigned (&XT)[16], const float* Ys, int i, int hi) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const h8_t xa = __builtin_bit_cast(h8_t, u4_t{XT[4 * t], XT[4 * t + 1], XT[4 * t + 2], XT[4 * t + 3]});
+        h8_t yb[NY], ys[NY];
+#pragma unroll
+        for (int n = 0; n < NY; ++n) {
+            yb[n] = wg16_frag(Ys, 32 * n + i, t, hi);
+            ys[n] = wg16_swap(yb[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NY; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, yb[n], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NY; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, ys[n], acc[n], 0, 0, 0);
+    }
+}
+
 // workgroup-wide max of a per-thread value through a shared word (all threads call; v >= 0)
 __device__ __forceinline__ float block_max(float v, unsigned* word) {
     __syncthreads();

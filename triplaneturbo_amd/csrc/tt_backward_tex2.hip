@@ -31,7 +31,7 @@
 // A fragment image = blocks [k-step][half-wave] of 32 samples x 8 halfs (the B fragment of a sample = one 16-byte row),
 // each block padded by 64 bytes: the transposed reads of tr_operand then spread over all 64 banks (block stride = 16
 // dwords mod 64, k-step stride = 32).  Every vector has a hi image and a lo image.
-#define P2_BLK 288                        /* halfs per block */
+#define P2_BLK FR_BLK                     /* halfs per block (tt_backward_common.h) */
 #define P2_EF_HALFS (6 * 2 * P2_BLK)      /* e: 6 k-steps */
 #define P2_XF_HALFS (4 * 2 * P2_BLK)      /* a 64-vector: 4 k-steps */
 #define P2_EF 0                           /* floats: hi image, lo image */
@@ -43,7 +43,11 @@
 #define P2_REGION (P2_FRAGS > 2 * P2_SCAT_FLOATS ? P2_FRAGS : 2 * P2_SCAT_FLOATS)
 #define P2_CTRL P2_REGION                 /* 16 ints: flags[2], any[2], item b (2), ck, ok; then cbar[2 waves][3][32] */
 #define P2_ES2 (P2_CTRL + 16 + 2 * 96)    /* Q rows of plane 2 (the wave whose turn it is): [32 samples][33] */
+#ifdef P2_EXP_TINY
+#define P2_PAIR_FLOATS 2048
+#else
 #define P2_PAIR_FLOATS (P2_ES2 + 32 * 33 + 8)
+#endif
 static_assert(SCATTER_M_FLOATS + 32 * 33 + 2 * 32 * 4 + SCATTER_TAG_INTS <= P2_SCAT_FLOATS, "scatter region too small");
 static_assert(3 * 32 * 8 <= P2_XF_HALFS, "gather tables must fit XF1");
 static_assert(16 * XS <= 4 * P2_BLK / 2, "the dV3 window (16 rows) must fit my own blocks of XF1");
@@ -90,24 +94,8 @@ __device__ __forceinline__ void pair_sync(PairCtx& pc, int lane) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 #define Z16 f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
 
-// fragments of one k-step: (hi, lo) 8 halfs each
-struct Frag {
-    h8_t h, l;
-};
-__device__ __forceinline__ Frag frag_lds(const half_t* img_h, const half_t* img_l, int ks, int hi, int j) {
-    Frag f;
-    f.h = *reinterpret_cast<const h8_t*>(img_h + (ks * 2 + hi) * P2_BLK + j * 8);
-    f.l = *reinterpret_cast<const h8_t*>(img_l + (ks * 2 + hi) * P2_BLK + j * 8);
-    return f;
-}
-__device__ __forceinline__ void frag_store(half_t* img_h, half_t* img_l, int ks, int hi, int j, const Frag& f) {
-    *reinterpret_cast<h8_t*>(img_h + (ks * 2 + hi) * P2_BLK + j * 8) = f.h;
-    *reinterpret_cast<h8_t*>(img_l + (ks * 2 + hi) * P2_BLK + j * 8) = f.l;
-}
 // my 16 registers (one 32-element half of a vector) -> the two k-steps' fragments under a per-launch scale
 template <int PAIR>
 __device__ __forceinline__ void split_half(const float (&x)[16], float sc, Frag (&f)[2]) {
@@ -130,48 +118,6 @@ __device__ __forceinline__ void mfma3(f32x16& acc, const h8_t ah, const h8_t al,
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.h, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.l, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.h, acc, 0, 0, 0);
-}
-
-// ---- outer-product operands straight from the fragment images: transposed LDS reads ----
-// An outer product over the samples wants, per lane = matrix row (or column), the 32 samples as k-slots; the images hold,
-// per sample, 8 elements as k-slots.  ds_read_b64_tr_b16 turns one into the other: a 16-lane group whose lane 4 j + q
-// points at the 8-byte piece q (half-wave block q & 1, upper / lower four slots q >> 1) of sample s0 + j receives, in lane
-// 4 q + e, slot e of that piece for the four samples j = 0..3.  Four reads cover this half-wave's 16 samples
-// (register 4 n + j <-> sample 16 hh' + 4 n + j); the hi and the lo image are read alike and zipped into (hi | lo << 16).
-// Which ELEMENT of the 32-element block a lane ends up with depends on the slot order of the image: identity for
-// PAIR_SEQ images, tr_elem() for PAIR_TR ones -- a permutation of the rows of the accumulated matrix, undone at the flush.
-__device__ __forceinline__ int tr_elem(int x) {  // lane x (0..31) of a PAIR_TR operand holds this element of the block
-    const int q = (x >> 2) & 3, e = x & 3;
-    return 16 * (x >> 4) + 2 * (e & 1) + 8 * (e >> 1) + (q >> 1) + 4 * (q & 1);
-}
-__device__ __forceinline__ void tr_operand(const half_t* img_h, const half_t* img_l, int blk, int lane, unsigned (&T)[16]) {
-    const int L = lane & 15, gg = lane >> 4, j = L >> 2, q = L & 3;
-    const int off = ((2 * blk + (gg & 1)) * 2 + (q & 1)) * P2_BLK + (16 * (gg >> 1) + j) * 8 + 4 * (q >> 1);  // halfs
-    const lds_sv4_t* ph = (const lds_sv4_t*)(img_h + off);
-    const lds_sv4_t* pl = (const lds_sv4_t*)(img_l + off);
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {  // four more samples per read: + 4 rows of 16 bytes
-        const sv4_t h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_sv4_t*>(ph) + 8 * n);
-        const sv4_t l4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_sv4_t*>(pl) + 8 * n);
-        const u2_t hu = __builtin_bit_cast(u2_t, h4), lu = __builtin_bit_cast(u2_t, l4);
-        T[4 * n + 0] = __builtin_amdgcn_perm(lu[0], hu[0], 0x05040100u);
-        T[4 * n + 1] = __builtin_amdgcn_perm(lu[0], hu[0], 0x07060302u);
-        T[4 * n + 2] = __builtin_amdgcn_perm(lu[1], hu[1], 0x05040100u);
-        T[4 * n + 3] = __builtin_amdgcn_perm(lu[1], hu[1], 0x07060302u);
-    }
-}
-// acc += X Y^T over the 32 samples (X, Y: transpose_block outputs)
-__device__ __forceinline__ void outer16(f32x16& acc, const unsigned (&X)[16], const unsigned (&Y)[16]) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const h8_t xa = __builtin_bit_cast(h8_t, u4_t{X[4 * g], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]});
-        const h8_t yb = __builtin_bit_cast(h8_t, u4_t{Y[4 * g], Y[4 * g + 1], Y[4 * g + 2], Y[4 * g + 3]});
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, yb, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, wg16_swap(yb), acc, 0, 0, 0);
-    }
-    // pin the persistent accumulator to the AGPR half of the register file: the allocator otherwise places these 16-wide
-    // tuples among the VGPRs, cannot keep five of them contiguous under pressure and spills them to scratch memory
-    asm volatile("" : "+a"(acc));
 }
 
 // ---- scatter of up to two planes by one wave (the straight-line, software-pipelined scheme of scatter_planes, with
@@ -308,9 +254,9 @@ __global__ __launch_bounds__(P2_THREADS, 2) void k_decode_bwd_tex2(BwdTexParams 
     }
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
-    // the wave index as a SCALAR (readfirstlane): everything derived from it -- H, the pair's LDS pointers, the branches on
-    // H -- is then wave-uniform for the compiler too (scalar registers and branches instead of vector ones)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // (the wave index stays a vector value for the compiler: made scalar with readfirstlane, the kernel spills 236 registers
+    // instead of 70 -- hipcc then turns the H-dependent selects into branches and keeps more state live across them)
+    const int wave = threadIdx.x >> 6;
     const int H = wave & 1;
     float* PR = Lt + TEX_W_FLOATS + (wave >> 1) * P2_PAIR_FLOATS;
     half_t* EFh = reinterpret_cast<half_t*>(PR + P2_EF);
