@@ -31,7 +31,7 @@ ELEM_VS_FP32 = 0.04  # and directly against the fp32 oracle at most 4 % of the e
 #                      bar against fp64 on 5 ... 97 % of the elements with worst elements 100 ... 18 000x their allowance.
 ELEM_VS_FP32_EXTREME = 0.08  # the one test with weight matrices scaled by 3e5 / 2e-6 / 7e4 (test_weight_matrices_of_any_scale:
 #                      measured 6.3 %, worst element 11x): the fp32 oracle's own intermediate values lose bits there
-NOISE32_CAP = 0.3   # fuzzed, ill-conditioned scenes: the HIP-vs-fp32 bar may widen to at most a quarter of the fp32 oracle's
+NOISE32_CAP = 0.3   # fuzzed, ill-conditioned scenes: the HIP-vs-fp32 bar may widen to at most 0.3 x the fp32 oracle's
 #                      own distance from fp64 (measured on fuzz seed 5, the only such case: 0.23 ... 0.26), and only where the exact_f32 kernels on the SAME inputs are as far from the
 #                      fp32 oracle (tests/test_gpu_fuzz.py records both): then it is the scene, not the operand split
 NAMES = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]

@@ -55,7 +55,7 @@ def test_random_configuration_matches_oracle(mods, seed):
     nz = [i for i, t in enumerate(g64) if float(t.abs().max()) > 0]  # (rgb_grad_shrink = 0, S = 1 ...: skip all-zero grads)
     names = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]
     # A default-path (split-fp16) case further than 1e-4 from the fp32 oracle is run again with the exact_f32 kernels on
-    # the SAME inputs: the wider bar below (<= a quarter of the fp32 oracle's own distance from fp64) is only granted when
+    # the SAME inputs: the wider bar below (<= NOISE32_CAP x the fp32 oracle's own distance from fp64) is only granted when
     # the fp32-MFMA path is as far away -- i.e. when the distance is the scene's conditioning, not the operand split.
     far = [i for i in nz if rel(g_hip[i], g32[i]) > TOL_VS_FP32]
     noise32 = 0.0
@@ -122,7 +122,7 @@ def test_random_point_query_matches_oracle(seed):
     names = ["points", "planes", "w1", "w2", "w3", "v1", "v2", "v3"]
     nz = [i for i, t in enumerate(g64) if float(t.abs().max()) > 0]
     check_grads(case, [g_hip[i].cpu().reshape(g64[i].shape) for i in nz], [g32[i] for i in nz], [g64[i] for i in nz],
-                names=[names[i] for i in nz], elem=False, noise32=NOISE32_CAP)
+                names=[names[i] for i in nz], elem=False)  # no widened bar: every case sits < 5e-5 from the fp32 oracle
 
 
 @pytest.mark.parametrize("seed", range(24))

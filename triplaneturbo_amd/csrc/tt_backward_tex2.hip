@@ -11,15 +11,24 @@
 //     there -- 4 ds_write_b128 + 4 ds_read_b128 per wave and exchange;
 //   * the accumulators are split too: wave H owns dV1[32 H .. , :] (48 registers), dV2[:, 32 H ..] (32) and dV3[:, 32 H ..];
 //   * the outer products take their [index][sample] operands NOT through an LDS transposition scratch but from the same
-//     fragments, transposed on the matrix cores: D = F x I (F = the fragment as A operand, I = a one-hot "identity" B
-//     operand) lands in the C/D layout lane <-> index, register <-> sample -- exactly the A / B operand layout of an
-//     outer product over the samples -- for the hi and the lo term separately (exact: one non-zero product per sum);
+//     fragment images, read TRANSPOSED by ds_read_b64_tr_b16 (tr_operand<> in tt_backward_common.h; the images are stored
+//     in the PAIR_TR register pairing and their rows are un-permuted at the flush, tr_elem()): an image written once
+//     serves the next product (B operand), the partner (exchange) and both outer products it takes part in;
 //   * the gather is split by samples (16 each), the plane-gradient scatter by planes (plane 0 / 1, plane 2 alternating).
-// => 80 accumulator registers + half-size vectors: <= 256 registers, two waves per SIMD; the pair synchronises six times
-// per tile step through sequence flags in LDS (no s_barrier: the pairs of a workgroup run independently).
+// => 80 accumulator registers + half-size vectors; three pairs per CU (384 threads, LDS-bound), 168 registers per wave;
+// the pair synchronises six times per tile step through sequence flags in LDS (no s_barrier: the pairs of a workgroup
+// run independently).
 // All split operands use PER-LAUNCH scales (rigorous bounds, as the outer products always did): one split serves the
 // product, the exchange and the outer product.  Default precision only; TT_R_EXACT_F32 / TT_R_WGRAD_F32 and the per-point
 // variant stay on k_decode_bwd_tex.
+//
+// STATUS (round 4, profiles/experiments/README.md "Round 4"): CORRECT -- every gradient within 1e-6 of the one-wave kernel
+// (tests/test_gpu_pair.py) -- but SLOWER: 4.31 ms against 2.93 ms on configs[1], so it is opt-in (TT_R_BWD_PAIR) and the
+// default stays k_decode_bwd_tex.  Measured causes: the code around the accumulators needs ~245 registers (gather
+// coefficients, scatter lists, fragment addressing), so at the 168-register cap of 3 waves / SIMD ~70 values live in
+// scratch and the accumulators are reloaded around the scatter; and a pair hand-off costs ~740 cycles of flag ping-pong
+// (tools/pair_sync_probe.hip), six times per tile step.  What a faster version needs is listed in DESIGN.md ("wave
+// pairs"): a <= 150-register non-accumulator body and fewer, coarser hand-offs.
 #include "tt_backward_common.h"
 
 #ifndef P2_PAIRS
