@@ -31,6 +31,10 @@ if os.environ.get("TT_SB_IMPORTANCE"):  # sweep of the tile shape used under imp
     for m in r.modules():
         if hasattr(m, "tile_sb_importance"):
             m.tile_sb_importance = int(os.environ["TT_SB_IMPORTANCE"])
+if os.environ.get("TT_SB_GLOBAL"):
+    r.tile_sb_global = int(os.environ["TT_SB_GLOBAL"])
+if os.environ.get("TT_SB_PATCH"):
+    r.tile_sb_patch = int(os.environ["TT_SB_PATCH"])
 gen = torch.Generator().manual_seed(1)
 cache = (torch.randn(P, 6, 32, 256, 256, generator=gen) * 0.5).to(dev).requires_grad_(True)
 ro, rd, c2w, cd = synthetic.make_cameras(P * NV, 128, 128)

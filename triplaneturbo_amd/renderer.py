@@ -121,7 +121,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         # kernel tile shape under importance sampling (performance only; not a reference knob, so not in Config).
         # Measured at the reference training shapes (42^2 + 40^2 rays, 193 samples): sb 1/2/4/8/16 =
         # 14.4/12.9/12.5/12.3/12.8 ms per PatchRenderer forward+backward.
-        self.tile_sb_importance = 8
+        self.tile_sb_importance = None  # None = by ray density (_tile_sb_for); an int pins it (performance only)
         # where the sampler places its edges in cdf space: "tt" | "center" (sampler.py; nerfacc's own convention is
         # unverifiable in this build, so the choice is explicit).  Not a reference knob, so not in Config.
         self.sampler_placement = "tt"
@@ -217,6 +217,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         assert B % P == 0, "batch of views must be a multiple of the number of prompts"
         grad_on = torch.is_grad_enabled()  # the reference stays differentiable in eval mode too
         packed = kwargs.pop("packed", None)  # PatchRenderer packs once for its two renders
+        tile_sb = kwargs.pop("tile_sb", None)  # PatchRenderer: its sparse global render and its dense patch differ
         if packed is None:
             with (torch.enable_grad() if grad_on else torch.no_grad()):
                 packed = ops.pack_planes(space_cache)
@@ -233,7 +234,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         sw, fw = self.geometry.mlp_weights()
         rc = self._render_config()
         if importance_sampled:  # consecutive samples crowd into the same texels: 2x2-pixel x 8-sample tiles
-            rc.tile_sb = self.tile_sb_importance
+            rc.tile_sb = int(tile_sb) if tile_sb is not None else self._tile_sb_for(rays_o.shape[2], space_cache.shape[-1])
         ctx = torch.enable_grad() if grad_on else torch.no_grad()
         with ctx:
             out = functional.volume_render(space_cache, sw, fw, rays_o, rays_d, t_starts, t_ends, bg_color,
@@ -243,6 +244,17 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         if self.training:
             out["inv_std"] = self.variance.inv_std
         return out
+
+    def _tile_sb_for(self, image_w: int, plane_w: int) -> int:
+        """Kernel tile shape under importance sampling (results do not depend on it).  Consecutive fine samples of a ray
+        crowd into the same texels, so sparse ray grids (adjacent pixels several texels apart: PatchRenderer's two
+        renders) want 2x2-pixel x 8-sample tiles; once adjacent pixels are less than about a texel apart (image at least
+        as wide as the planes) the 4x4-pixel x 2-sample tile of uniform sampling shares more texels: measured on
+        configs[1] with the 128 + 64 sampler, 256^2 rays on 256^2 planes, 12.8 (sb 2) / 13.8 (4) / 14.9 (8) / 17.2 (16)
+        ms per step; training shapes (42^2 + 40^2 rays) 9.0 / 8.8 / 8.8 / 8.9 (tools/time_training_shapes.py)."""
+        if self.tile_sb_importance is not None:
+            return int(self.tile_sb_importance)
+        return 2 if image_w >= plane_w else 8
 
     def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False) -> None:
         self._inv_std_cache = (None, None)  # one read-back per step at most; also catches `.data` writes
@@ -281,6 +293,9 @@ class PatchRenderer(BaseModule):
     def configure(self, geometry, material, background) -> None:
         self.base_renderer = find(self.cfg.base_renderer_type)(self.cfg.base_renderer, geometry=geometry,
                                                                material=material, background=background)
+        # kernel tile shapes of the two renders (performance only; None = the base renderer's choice)
+        self.tile_sb_global = None
+        self.tile_sb_patch = None
 
     def forward(self, rays_o: Tensor, rays_d: Tensor, light_positions: Optional[Tensor] = None,
                 bg_color: Optional[Tensor] = None, **kwargs) -> Dict[str, Tensor]:
@@ -294,12 +309,14 @@ class PatchRenderer(BaseModule):
         ds = self.cfg.global_downsample
         g_o = F.interpolate(rays_o.permute(0, 3, 1, 2), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
         g_d = F.interpolate(rays_d.permute(0, 3, 1, 2), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
-        out_global = self.base_renderer(g_o.contiguous(), g_d.contiguous(), light_positions, bg_color, **kwargs)
+        kw_g = kwargs if self.tile_sb_global is None else dict(kwargs, tile_sb=self.tile_sb_global)
+        kw_p = kwargs if self.tile_sb_patch is None else dict(kwargs, tile_sb=self.tile_sb_patch)
+        out_global = self.base_renderer(g_o.contiguous(), g_d.contiguous(), light_positions, bg_color, **kw_g)
         PS = self.cfg.patch_size
         px = torch.randint(0, W - PS, (1,)).item()
         py = torch.randint(0, H - PS, (1,)).item()
         out = self.base_renderer(rays_o[:, py:py + PS, px:px + PS].contiguous(),
-                                 rays_d[:, py:py + PS, px:px + PS].contiguous(), light_positions, bg_color, **kwargs)
+                                 rays_d[:, py:py + PS, px:px + PS].contiguous(), light_positions, bg_color, **kw_p)
         eager = out.eager_keys() if hasattr(out, "eager_keys") else list(out)  # per-sample extras stay lazy
         valid = [k for k in eager if torch.is_tensor(out[k]) and out[k].ndim == out["comp_rgb"].ndim
                  and out[k][..., 0].shape == out["comp_rgb"][..., 0].shape]
