@@ -34,11 +34,18 @@ struct BwdGeoParams {
 };
 
 #define GEO_SCRATCH_FLOATS (2 * 64 * XS)
-// split-fp16 weight images (tt_mfma16.h): W1, W2 at their fp32 offsets (same bytes); the transposed products read them
-// through ds_read_b64_tr_b16 (mv16t)
-#define LDS_GEO16_FLOATS LDS_GEO_FLOATS
+// split-fp16 weight images (tt_mfma16.h): W1, W2 at their fp32 offsets (same bytes); the transposed products use
+// transposed COPIES appended to them (TT_BWD_WT_COPIES, tt_backward_common.h: 26 KB of LDS nothing else wants at one wave
+// per SIMD) or, without, read the forward images through ds_read_b64_tr_b16 (mv16t)
+#define GOFF_W1T LDS_GEO_FLOATS
+#define GOFF_W2T (GOFF_W1T + IMG16_FLOATS(32, 64))
+#define LDS_GEO16_FLOATS (TT_BWD_WT_COPIES ? GOFF_W2T + IMG16_FLOATS(64, 64) : LDS_GEO_FLOATS)
+#define GEO_PAIR (TT_BWD_WT_COPIES ? PAIR_SEQ : PAIR_TR)
 
-template <bool EXACT, bool WG16>
+// STATS: the work accounting (tt_render_cfg.stats) compiled in.  In this kernel even a never-taken scalar branch per
+// counting site costs 2-3 % (2.95 vs 2.85 ms: the branches cut hipcc's scheduling regions), so production launches
+// (stats == null) run the instantiation without it.
+template <bool EXACT, bool WG16, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     __shared__ __attribute__((aligned(16))) float L[LDS_GEO16_FLOATS + 4 * (GEO_SCRATCH_FLOATS + SCATTER_TAG_INTS)];
     {
@@ -46,6 +53,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
         stage_weights<EXACT, 64, 64>(L + OFF_W2, w.w2);
         lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
+        if (TT_BWD_WT_COPIES) {
+            stage_weights_t<EXACT, 64, 32>(L + GOFF_W1T, w.w1);
+            stage_weights_t<EXACT, 64, 64>(L + GOFF_W2T, w.w2);
+        }
     }
     const tt_render_cfg& cfg = p.cfg;
     // ---- per-launch operand scales of the fp16 outer products dW1 += a1 u^T, dW2 += a2 v^T (wgrad16 above) ----
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
     const unsigned grad_bytes = (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
 
-    TileStats st = {0, 0, 0};
+    const TileStats st = STATS ? tile_stats(cfg.stats) : TileStats{nullptr};
     f32x16 accW1[2][1] = {{ZERO16}, {ZERO16}};
     f32x16 accW2[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};
     float accw3 = 0.f;
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             // that the scalar ALU has just combined (see corners_setup in tt_device.h)
             const float vf = ray_okf * (si < s_end ? 1.f : 0.f);
             const float sbar = in.up[0] * vf, gbx = in.up[1] * vf, gby = in.up[2] * vf, gbz = in.up[3] * vf;
-            st.visited += 1;
+            tile_stat(st, TT_STAT_VISITED);
             TT_PHASE(0);
             // exact with skip_eps_geo = 0 (the default); > 0: the opt-in approximation of tt_abi.h.  (!(x <= eps): a NaN
             // upstream is never skipped)
@@ -162,10 +173,11 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             float f[16], u[16];  // u = sbar f + J gbar
             bool anyp[3];
             const bool any = __any(gather_geo_bwd_c(p.packed, (unsigned)(pofs / TT_C), H, W, X, Y, Z, rvalid, sbar, gbx,
-                                                    gby, gbz, ju, jv, lane, Xs, f, u, anyp, &st.inbounds));
+                                                    gby, gbz, ju, jv, lane, Xs, f, u, anyp,
+                                                    tile_stat_ptr(st, TT_STAT_INBOUNDS)));
             TT_PHASE(1);
             if (!any) continue;  // exact: no in-bounds texel => f = J = 0, every mask false
-            st.executed += 1;
+            tile_stat(st, TT_STAT_EXECUTED);
             float h1[32], h2[32], a2[32], a1[32], q[16];
             mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
@@ -180,18 +192,30 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
             }
             // a2 and a1 feed a product AND an outer product (dW2, dW1): split once under the per-launch scales
-            Split16<64, PAIR_TR> a2s, a1s;  // (consumed by the transposed products and the outer-product staging)
+            Split16<64, GEO_PAIR> a2s, a1s;  // (consumed by the transposed products and the outer-product staging)
             if (WG16) {
-                split16_vec<64, PAIR_TR>(a2, sA2, a2s);
+                split16_vec<64, GEO_PAIR>(a2, sA2, a2s);
+#if TT_BWD_WT_COPIES
+                mv16_pre<64, 64>(L + GOFF_W2T, a2s, 1.f / sA2, a1, i, hi);
+#else
                 mv16t_pre<64, 64, 64>(L + OFF_W2, 0, a2s, 1.f / sA2, a1, lane);
+#endif
+            } else if constexpr (TT_BWD_WT_COPIES) {
+                mvtx_copy<EXACT, 64, 64, 64>(L + GOFF_W2T, L + OFF_W2, a2, a1, i, hi);
             } else {
                 mvtx<EXACT, 64, 64, 64>(L + OFF_W2, 0, a2, a1, i, hi);
             }
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
             if (WG16) {
-                split16_vec<64, PAIR_TR>(a1, sA1, a1s);
+                split16_vec<64, GEO_PAIR>(a1, sA1, a1s);
+#if TT_BWD_WT_COPIES
+                mv16_pre<32, 64>(L + GOFF_W1T, a1s, 1.f / sA1, q, i, hi);
+#else
                 mv16t_pre<32, 64, 32>(L + OFF_W1, 0, a1s, 1.f / sA1, q, lane);
+#endif
+            } else if constexpr (TT_BWD_WT_COPIES) {
+                mvtx_copy<EXACT, 32, 64, 32>(L + GOFF_W1T, L + OFF_W1, a1, q, i, hi);
             } else {
                 mvtx<EXACT, 32, 64, 32>(L + OFF_W1, 0, a1, q, i, hi);
             }
@@ -287,7 +311,6 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     flush_wgrad_reduced<64, 32>(L, parity, accW1, p.grads.w1, wave_in_blk, lane, 1.f / sA1, 1.f / sU);
     flush_wgrad_reduced<64, 64>(L, parity, accW2, p.grads.w2, wave_in_blk, lane, 1.f / sA2, 1.f / sV);
     atomicAdd(p.grads.w3 + lane, accw3);
-    tile_stats_flush(cfg.stats, st);
 }
 
 #ifdef TT_TUNING
@@ -317,11 +340,20 @@ static void launch_bwd_geo(const BwdGeoParams& p0, long long blocks, hipStream_t
         const long long n = p.cfg.n_rays * p.cfg.n_samples;  // upstream float4 (d sdf, d sdf_grad) per sample
         hipLaunchKernelGGL(k_absmax4, dim3(absmax_blocks(n), 1), dim3(256), 0, s, reinterpret_cast<const f32x4*>(p.ws), n, n,
                            bnd + TT_BOUND_UP0, bnd + TT_BOUND_UP1);
-        hipLaunchKernelGGL((k_decode_bwd_geo<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        if (p.cfg.stats)
+            hipLaunchKernelGGL((k_decode_bwd_geo<false, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((k_decode_bwd_geo<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     } else if (p.cfg.flags & TT_R_EXACT_F32) {
-        hipLaunchKernelGGL((k_decode_bwd_geo<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        if (p.cfg.stats)
+            hipLaunchKernelGGL((k_decode_bwd_geo<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((k_decode_bwd_geo<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL((k_decode_bwd_geo<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        if (p.cfg.stats)
+            hipLaunchKernelGGL((k_decode_bwd_geo<false, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((k_decode_bwd_geo<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     }
 }
 int tt_launch_march_bwd(const float* rays_d, const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,

@@ -701,11 +701,18 @@ struct BwdTexParams {
 #define TV1 0
 #define TV2 (OFF_V2 - OFF_V1)
 #define TV3 (OFF_V3 - OFF_V1)
-// V1, V2 as split-fp16 images (tt_mfma16.h): every mat-vec product of the kernel runs on the fp16 pipe; the V2^T / V1^T
-// products read the same images through ds_read_b64_tr_b16 (mv16t; rounds 2-3 kept 43 KB of transposed copies here).
+// V1, V2 as split-fp16 images (tt_mfma16.h): every mat-vec product of the kernel runs on the fp16 pipe.  The V2^T / V1^T
+// products either read the same images through ds_read_b64_tr_b16 (mv16t: the wave-pair kernel, where LDS is what limits
+// the pairs per CU) or use transposed COPIES (TT_BWD_WT_COPIES, the one-wave kernels' default: 43 KB more LDS that nothing
+// else wants at one wave per SIMD, and plain ds_read_b128 fragments: texture backward 2.94 -> 2.85 ms, bit-identical).
 // The per-wave scratch is 128 rows: the parked e (96 rows) shares it with a 32-row window through which k2 (for dV3)
 // and k1bar (for dV1) are transposed in two halves.
-#define TEX_W16_FLOATS TEX_W_FLOATS
+#ifndef TT_BWD_WT_COPIES
+#define TT_BWD_WT_COPIES 1
+#endif
+#define TV1T TEX_W_FLOATS
+#define TV2T (TV1T + IMG16_FLOATS(96, 64))
+#define TEX_W16_FLOATS (TT_BWD_WT_COPIES ? TV2T + IMG16_FLOATS(64, 64) : TEX_W_FLOATS)
 void tt_launch_bwd_tex2(const BwdTexParams& p, int cus, hipStream_t s);  // tt_backward_tex2.hip
 
 // =====================================================================================================

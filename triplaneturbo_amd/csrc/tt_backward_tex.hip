@@ -15,6 +15,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         stage_weights<EXACT, 64, 96>(Lt + TV1, w.v1);
         stage_weights<EXACT, 64, 64>(Lt + TV2, w.v2);
         lds_load_matrix(Lt + TV3, w.v3, 3, 64, 64);
+        if (TT_BWD_WT_COPIES) {
+            stage_weights_t<EXACT, 64, 96>(Lt + TV1T, w.v1);
+            stage_weights_t<EXACT, 64, 64>(Lt + TV2T, w.v2);
+        }
     }
     const tt_render_cfg& cfg = p.cfg;
     // ---- per-launch operand scales of the fp16 outer products dV1 += k1bar e^T, dV2 += k2bar k1^T (wgrad16) ----
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
     const unsigned grad_bytes = (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
 
-    TileStats st = {0, 0, 0};
+    const TileStats st = tile_stats(cfg.stats);
     f32x16 accV1a[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};  // dV1[:, 0:64]
     f32x16 accV1b[2][1] = {{ZERO16}, {ZERO16}};                  // dV1[:, 64:96]
     f32x16 accV2[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             const float c = shrink * in.wgt * grgb[o] * 1.002f * s * (1.f - s) + in.gf[o];
             cb[o] = c * vf;  // 0/1 factor, not a select on a freshly combined lane mask (see k_decode_bwd_geo)
         }
-        st.visited += 1;
+        tile_stat(st, TT_STAT_VISITED);
         TT_PHASE(0);
         // exact with skip_eps_tex = 0 (the default: nothing flows back); > 0: the opt-in approximation of tt_abi.h
         if (!__any(!((__builtin_fabsf(cb[0]) + __builtin_fabsf(cb[1])) + __builtin_fabsf(cb[2]) <= cfg.skip_eps_tex)))
@@ -155,10 +159,11 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius), Z = scale_coord(pz, cfg.radius);
         float e[48];
         const bool any =
-            __any(gather_tex_c(p.packed, (unsigned)(pofs / TT_C), H, W, X, Y, Z, valid, lane, Xs, e, &st.inbounds));
+            __any(gather_tex_c(p.packed, (unsigned)(pofs / TT_C), H, W, X, Y, Z, valid, lane, Xs, e,
+                               tile_stat_ptr(st, TT_STAT_INBOUNDS)));
         TT_PHASE(1);
         if (!any) continue;  // exact: e == 0 => k1 = k2 = 0 and every mask is false
-        st.executed += 1;
+        tile_stat(st, TT_STAT_EXECUTED);
         // e is needed again only as the Y operand of the dV1 outer product: park it in LDS now ([idx][sample]
         // layout, 96 rows) so its 48 registers are free during the MLP chain.
         // (`region`: always true -- tt_validate_cfg rejects negative flags -- but opaque to the compiler.  The two
@@ -234,7 +239,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         }
         // ---- k1bar = n1 . (V2^T k2bar) ----
         float kb1[32];
-        mvtx<EXACT, 64, 64, 64>(Lt + TV2, 0, k2, kb1, i, hi);
+        if constexpr (TT_BWD_WT_COPIES)
+            mvtx_copy<EXACT, 64, 64, 64>(Lt + TV2T, Lt + TV2, k2, kb1, i, hi);
+        else
+            mvtx<EXACT, 64, 64, 64>(Lt + TV2, 0, k2, kb1, i, hi);
 #pragma unroll
         for (int r = 0; r < 32; ++r) kb1[r] = k1[r] > 0.f ? kb1[r] : 0.f;
         TT_PHASE(6);
@@ -284,7 +292,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             scatter_clear<SC_EXACT>(M, lane);
             // ebar = V1^T k1bar for the three planes in ONE product (96 rows: k1bar is split into fp16 terms once)
             float eb[48];
-            mvtx<EXACT, 96, 64, 96>(Lt + TV1, 0, kb1, eb, i, hi);
+            if constexpr (TT_BWD_WT_COPIES)
+                mvtx_copy<EXACT, 96, 64, 96>(Lt + TV1T, Lt + TV1, kb1, eb, i, hi);
+            else
+                mvtx<EXACT, 96, 64, 96>(Lt + TV1, 0, kb1, eb, i, hi);
             TT_PHASE(9);
             const int tex0 = (int)(pofs / TT_C);
             scatter_planes<SC_EXACT>(grad_out, grad_bytes, Es, M, tags, Es + 32 * 33, i, hi, [&](int pl, PlaneRefs& refs) {
@@ -338,7 +349,6 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
         for (int o = 0; o < 3; ++o) atomicAdd(p.grads.v3 + o * 64 + 32 * h2 + i, accV3[h2][o]);
-    tile_stats_flush(cfg.stats, st);
 }
 
 static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t s) {

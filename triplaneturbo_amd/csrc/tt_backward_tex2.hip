@@ -308,7 +308,7 @@ __global__ __launch_bounds__(P2_THREADS, 2) void k_decode_bwd_tex2(BwdTexParams 
     f32x16 accV1[3] = {Z16, Z16, Z16};  // dV1[32 H + row][32 p + col]
     f32x16 accV2[2] = {Z16, Z16};       // dV2[32 m + row][32 H + col]
     float accV3[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // dV3[o][32 H + 16 a + (lane & 15)], this lane: 8 samples
-    TileStats st = {0, 0, 0};
+    const TileStats st = tile_stats(cfg.stats);
 #ifdef TT_TUNING
     unsigned long long ph_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long ph_t = __builtin_amdgcn_s_memtime();
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(P2_THREADS, 2) void k_decode_bwd_tex2(BwdTexParams 
                 const float c = shrink * in.wgt * grgb[o] * 1.002f * s * (1.f - s) + in.gf[o];
                 cb[o] = c * vf;
             }
-            if (H == 0) st.visited += 1;
+            if (H == 0) tile_stat(st, TT_STAT_VISITED);
             P2_PHASE(0);
             if (!__any(!((__builtin_fabsf(cb[0]) + __builtin_fabsf(cb[1])) + __builtin_fabsf(cb[2]) <= cfg.skip_eps_tex)))
                 continue;  // (the same decision in both waves: same data)
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(P2_THREADS, 2) void k_decode_bwd_tex2(BwdTexParams 
                 const float gu = pl == 2 ? Zs_ : Xs_, gv = pl == 1 ? Zs_ : Ys_;
                 corners_setup(gu, gv, Hp, Wp, vfs != 0.f, cn);
                 const unsigned long long inm = __ballot(cn.any);
-                st.inbounds += (unsigned)__popcll(inm & 0x0000ffffffffffffull);
+                tile_stat(st, TT_STAT_INBOUNDS, (unsigned)__popcll(inm & 0x0000ffffffffffffull));
                 if (lane < 48) {
                     const unsigned bb = (unsigned)tex0s + (unsigned)((3 + pl) * HW);
                     const ti32x4 o4 = {(int)(bb + cn.off[0]), (int)(bb + cn.off[1]), (int)(bb + cn.off[2]),
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(P2_THREADS, 2) void k_decode_bwd_tex2(BwdTexParams 
                 pair_sync(pc, lane);  // both have read the flags before the next gather rewrites them
                 continue;             // exact: e == 0 for the whole tile
             }
-            if (H == 0) st.executed += 1;
+            if (H == 0) tile_stat(st, TT_STAT_EXECUTED);
 
             // ================= k1 half = relu(V1[32 H .., :] e) =================
             unsigned n1 = 0;  // bit r: k1[r] > 0 (the ReLU mask k1bar needs; the values live on as fragments only)
@@ -682,7 +682,6 @@ __global__ __launch_bounds__(P2_THREADS, 2) void k_decode_bwd_tex2(BwdTexParams 
 #pragma unroll
             for (int o = 0; o < 3; ++o) atomicAdd(p.grads.v3 + o * 64 + 32 * H + 16 * a + (lane & 15), accV3[a][o]);
     }
-    tile_stats_flush(cfg.stats, st);
 #ifdef TT_TUNING
     P2_PHASE(16);
     if (p.phase_cycles && lane == 0)

@@ -369,21 +369,29 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
     return any;
 }
 
-// Work accounting (tt_render_cfg.stats): per-wave counters in scalar registers -- the values are wave-uniform (ballots,
-// pop-counts), so counting costs a few SALU instructions per tile step and nothing on the vector pipes.  Flushed with one
-// atomic per counter per wave at kernel end, and only when the caller asked (stats != null).
+// Work accounting (tt_render_cfg.stats, measurement only).  NOTHING is kept in registers: the pointer is a kernel argument
+// (wave-uniform), so a production launch (null) pays one scalar branch per counting site, and a measuring launch adds
+// to the counters in memory with one atomic per site and wave.  (Round 4 first kept per-wave counters in registers and
+// flushed them at kernel end: 0.09 ms of the 7.85 ms step -- the decode kernels have no registers to spare.)
 struct TileStats {
-    unsigned long long visited;   // tile steps popped and looked at
-    unsigned long long executed;  // tile steps that passed every exact skip test and ran the MLP chain
-    unsigned long long inbounds;  // (plane, sample) pairs with an in-bounds texel, over the gathers that ran
+    unsigned long long* p;  // null, or the caller's 4 counters: [0] visited, [1] executed, [2] in-bounds pairs
 };
-__device__ __forceinline__ void tile_stats_flush(uint64_t* stats64, const TileStats& s) {
-    unsigned long long* stats = reinterpret_cast<unsigned long long*>(stats64);
-    if (stats && (threadIdx.x & 63) == 0) {
-        atomicAdd(stats + 0, s.visited);
-        atomicAdd(stats + 1, s.executed);
-        atomicAdd(stats + 2, s.inbounds);
+enum { TT_STAT_VISITED = 0, TT_STAT_EXECUTED = 1, TT_STAT_INBOUNDS = 2 };
+__device__ __forceinline__ TileStats tile_stats(uint64_t* stats64) {
+#ifdef TT_NO_STATS  // dev A/B only (tools/build_variants.py): what the counting costs
+    return TileStats{nullptr};
+#else
+    return TileStats{reinterpret_cast<unsigned long long*>(stats64)};
+#endif
+}
+// wave-uniform `v`; one lane adds
+__device__ __forceinline__ void tile_stat(const TileStats& st, int which, unsigned v = 1) {
+    if (st.p) {
+        if ((threadIdx.x & 63) == 0) atomicAdd(st.p + which, (unsigned long long)v);
     }
+}
+__device__ __forceinline__ unsigned long long* tile_stat_ptr(const TileStats& st, int which) {
+    return st.p ? st.p + which : nullptr;
 }
 
 // ---- coalesced gathers ------------------------------------------------------------------------------------------------
@@ -459,7 +467,9 @@ __device__ __forceinline__ bool gather_geo_c(const float* __restrict__ planes, u
         corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, cn);
         any = any || cn.any;
         const unsigned long long inmask = __ballot(cn.any);
-        if (inb) *inb += (unsigned)__popcll(inmask & 0xffffffffull);
+        if (inb) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(inb, (unsigned long long)__popcll(inmask & 0xffffffffull));
+        }
         if (inmask == 0) continue;  // exact: every contribution of this plane is 0 for the whole tile
         if (hi == 0) {
             const unsigned b = tex0 + (unsigned)(p * HW);
@@ -575,7 +585,9 @@ __device__ __forceinline__ bool gather_tex_c(const float* __restrict__ planes, u
         Corners cn;
         corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, cn);
         const unsigned long long inmask = __ballot(cn.any);
-        if (inb) *inb += (unsigned)__popcll(inmask & 0xffffffffull);
+        if (inb) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(inb, (unsigned long long)__popcll(inmask & 0xffffffffull));
+        }
         anyp[p] = inmask != 0;
         any = any || cn.any;
         if (hi == 0) {
@@ -657,7 +669,9 @@ __device__ __forceinline__ bool gather_geo_bwd_c(const float* __restrict__ plane
         float coef[4];
         geo_corner_coefs(p, H, W, X, Y, Z, valid, sbar, gux, guy, guz, jscale_u, jscale_v, cn, coef);
         const unsigned long long inmask = __ballot(cn.any);
-        if (inb) *inb += (unsigned)__popcll(inmask & 0xffffffffull);
+        if (inb) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(inb, (unsigned long long)__popcll(inmask & 0xffffffffull));
+        }
         anyp[p] = inmask != 0;
         any = any || cn.any;
         if (hi == 0) {

@@ -136,7 +136,7 @@ struct DecodeCfg {
     float radius;
     float ju, jv;  // 0.5*W/radius, 0.5*H/radius
     int dbg;       // profiling-only ablation flags
-    TileStats* st = nullptr;  // work accounting of the render kernels (tt_render_cfg.stats), else null
+    TileStats st = {nullptr};  // work accounting of the render kernels (tt_render_cfg.stats), else null
 };
 
 // outputs are identical in both half-waves.  gq = J^T q (WITHOUT the sphere term).
@@ -177,7 +177,7 @@ __device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& 
     gq[0] = gq[1] = gq[2] = 0.f;
     float f[16], jx[16], jy[16], jz[16];
     bool any = gather_geo_c<NEED_N>(dc.planes, dc.tex0, dc.H, dc.W, X, Y, Z, valid, dc.ju, dc.jv, 32 * hi + i, dc.T, f, jx,
-                                 jy, jz, dc.st ? &dc.st->inbounds : nullptr);
+                                 jy, jz, tile_stat_ptr(dc.st, TT_STAT_INBOUNDS));
     if (TT_DBG(dc.dbg, TT_DBG_NO_MLP)) {
         float t = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
 #pragma unroll
@@ -192,7 +192,7 @@ __device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& 
         gq[1] = ty;
         gq[2] = tz;
     } else if (__any(any)) {
-        if (dc.st) dc.st->executed += 1;
+        tile_stat(dc.st, TT_STAT_EXECUTED);
         float h1[32], h2[32];
         mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
 #pragma unroll
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
     const int S = cfg.n_samples;
     ItemQueue iq = item_queue(p.queue, tg.n_blocks, tg.n_chunks, tg.unit);
     const size_t plane_stride = (size_t)6 * cfg.plane_h * cfg.plane_w * TT_C;
-    TileStats st = {0, 0, 0};
+    const TileStats st = tile_stats(cfg.stats);
 
 #pragma nounroll
     for (;;) {
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
         const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
         const int view = (int)(ray / cfg.rays_per_view);
         DecodeCfg dc;
-        dc.st = &st;
+        dc.st = st;
         dc.planes = p.packed;
         dc.tex0 = (unsigned)((size_t)(view / cfg.views_per_prompt) * (plane_stride / TT_C));
         dc.T = T;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
         for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb) {
             const int si = sb0 + ks;
             const bool rvalid = ray_ok && si < s_end;
-            st.visited += 1;
+            tile_stat(st, TT_STAT_VISITED);
             const long long sidx = ray * S + (si < S ? si : S - 1);
             const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
             float tm, px, py, pz;
@@ -489,7 +489,6 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
             }
         }
     }
-    tile_stats_flush(cfg.stats, st);
 }
 
 // =====================================================================================================

@@ -419,6 +419,15 @@ __device__ __forceinline__ void stage_weights(float* dst_f, const float* __restr
     }
 }
 
+// image of src^T (src is ROWS_SRC x K_SRC row-major) for kernels that keep a transposed COPY for their `M^T x` products
+// instead of reading the forward image through ds_read_b64_tr_b16: the one-wave backward kernels, where LDS is not scarce
+// (occupancy is register-bound) and ds_read_b128 fragments issue at twice the rate of the transposed reads.  Nothing to
+// do when EXACT.
+template <bool EXACT, int ROWS_SRC, int K_SRC>
+__device__ __forceinline__ void stage_weights_t(float* dst_f, const float* __restrict__ src) {
+    if constexpr (!EXACT) stage_image16<K_SRC, ROWS_SRC, true>(dst_f, src, K_SRC);
+}
+
 // y[NOUT] = M[NOUT][NIN] x
 template <bool EXACT, int NOUT, int NIN>
 __device__ __forceinline__ void mvx(const float* img, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i, int hi) {
@@ -426,6 +435,16 @@ __device__ __forceinline__ void mvx(const float* img, const float (&x)[NIN / 2],
         mv_fwd<NOUT, NIN>(img, x, y, i, hi);
     } else {
         mv16<NOUT, NIN>(img, x, y, i, hi);
+    }
+}
+// y[NOUT] = M^T x with `img_t` the split-fp16 image of M^T (stage_weights_t) and `img` the fp32 image of M (EXACT)
+template <bool EXACT, int NOUT, int NIN, int KM>
+__device__ __forceinline__ void mvtx_copy(const float* img_t, const float* img, const float (&x)[NIN / 2],
+                                          float (&y)[NOUT / 2], int i, int hi) {
+    if constexpr (EXACT) {
+        mv_bwd<NOUT, NIN, KM + 4>(img, x, y, i, hi);
+    } else {
+        mv16<NOUT, NIN>(img_t, x, y, i, hi);
     }
 }
 // y[NOUT] = M[:, col0 .. col0 + NOUT)^T x for M (NIN rows, KM columns) staged by stage_weights at `img`: from the fp32
