@@ -361,14 +361,34 @@ extern "C" int tt_composite_bwd(const float* opacity, const float* depth, const 
 // instead -- correct, just not bit-reproducible.  acc: 4 zeroed ints of the launch's scratch slot (tt_host.h):
 // [0..1] the accumulator, [2] the overflow float, [3] the arrival counter.
 #define TT_EIK_FRAC 0x1p44
+// VEC (g 16-byte aligned): a thread takes FOUR samples = three float4 per iteration, two iterations in flight: the scalar
+// form (three 4-byte loads per sample, one sample in flight per thread) reached 2.2 TB/s, 45 us for the 100 MB of the
+// headline size.  The per-thread order of the additions is fixed either way: bit-reproducible.
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_eikonal_fwd(const float* __restrict__ g, long long n, double inv_n,
                                                      int* __restrict__ acc, float* __restrict__ out) {
     double sum = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float x = g[i * 3 + 0], y = g[i * 3 + 1], z = g[i * 3 + 2];
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    auto term = [](float x, float y, float z) {
         const float d = sqrtf(x * x + y * y + z * z) - 1.f;
-        sum += (double)(d * d);
+        return (double)(d * d);
+    };
+    long long done = 0;
+    if (VEC) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+        const long long n4 = n / 4;
+#pragma unroll 2
+        for (long long q = tid; q < n4; q += nth) {
+            const f32x4 a = g4[3 * q], b = g4[3 * q + 1], c = g4[3 * q + 2];
+            sum += term(a[0], a[1], a[2]);
+            sum += term(a[3], b[0], b[1]);
+            sum += term(b[2], b[3], c[0]);
+            sum += term(c[1], c[2], c[3]);
+        }
+        done = 4 * n4;
     }
+    for (long long i = done + tid; i < n; i += nth) sum += term(g[i * 3 + 0], g[i * 3 + 1], g[i * 3 + 2]);
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     __shared__ double part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
@@ -411,8 +431,12 @@ extern "C" int tt_eikonal_fwd(const float* sdf_grad, int64_t n, float* loss, voi
     if (blocks > 512) blocks = 512;  // one same-address atomic per workgroup: they serialise at ~11 ns each
     int* slot = tt_queue_counters(s);  // zeroed on the stream in front of this launch
     if (!slot) return TT_ERR_DEVICE;
-    hipLaunchKernelGGL(k_eikonal_fwd, dim3((unsigned)blocks), dim3(256), 0, s, sdf_grad, (long long)n, 1.0 / (double)n,
-                       slot + TT_SLOT_EIKONAL, loss);
+    if ((reinterpret_cast<uintptr_t>(sdf_grad) & 15) == 0)
+        hipLaunchKernelGGL(k_eikonal_fwd<true>, dim3((unsigned)blocks), dim3(256), 0, s, sdf_grad, (long long)n,
+                           1.0 / (double)n, slot + TT_SLOT_EIKONAL, loss);
+    else
+        hipLaunchKernelGGL(k_eikonal_fwd<false>, dim3((unsigned)blocks), dim3(256), 0, s, sdf_grad, (long long)n,
+                           1.0 / (double)n, slot + TT_SLOT_EIKONAL, loss);
     return tt_check_launch();
 }
 
