@@ -115,12 +115,24 @@ __device__ __forceinline__ float wg16_scale(float bound) {
     return __builtin_bit_cast(float, (unsigned)(268 - E) << 23);
 }
 __device__ __forceinline__ unsigned wg16_pack(float x) {  // (hi | lo << 16), both round-to-nearest-even: hi + lo ~ x
+#if TT_SPLIT_PAIR_ASM
+    // three instructions in one block (see split_pair, tt_mfma16.h): hi = f16(x); r = x * 1.0 - hi (exact); pack(x, r)
+    unsigned out;
+    float r;
+    asm("v_cvt_pk_f16_f32 %0, %2, 0\n\t"
+        "v_fma_mix_f32 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_pk_f16_f32 %0, %2, %1"
+        : "=&v"(out), "=&v"(r)
+        : "v"(x));
+    return out;
+#else
     const float hf = (float)cvt_pk16(x, 0.f).x;
 #if TT_SPLIT_MODE != 2
     return cvt_pk16u(x, x - hf);  // (both halves with the same rounding: one packed convert)
 #else
     const unsigned h = cvt_pk16u(x, 0.f), l = cvt_pk16u_lo(x - hf, 0.f);
     return (h & 0xffffu) | (l << 16);
+#endif
 #endif
 }
 template <int N>
@@ -619,8 +631,8 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float x0 = bs[ks][2 * j] * bsc, x1 = bs[ks][2 * j + 1] * bsc;
-                    const h2_t ph = cvt_pk16(x0, x1);
-                    const h2_t pq = cvt_pk16_lo(x0 - (float)ph.x, x1 - (float)ph.y);
+                    h2_t ph, pq;
+                    split_pair(x0, x1, ph, pq);
                     bh[ks][2 * j] = ph.x;
                     bh[ks][2 * j + 1] = ph.y;
                     bl[ks][2 * j] = pq.x;

@@ -7,7 +7,8 @@
 // =====================================================================================================
 #define TEX_SCRATCH_FLOATS (128 * XS)
 
-template <bool EXACT, bool WG16>
+// STATS: work accounting compiled in (see k_decode_bwd_geo): production launches run the instantiation without it
+template <bool EXACT, bool WG16, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     __shared__ __attribute__((aligned(16))) float Lt[TEX_W16_FLOATS + 4 * (TEX_SCRATCH_FLOATS + SCATTER_TAG_INTS)];
     {
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
     const unsigned grad_bytes = (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
 
-    const TileStats st = tile_stats(cfg.stats);
+    const TileStats st = STATS ? tile_stats(cfg.stats) : TileStats{nullptr};
     f32x16 accV1a[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};  // dV1[:, 0:64]
     f32x16 accV1b[2][1] = {{ZERO16}, {ZERO16}};                  // dV1[:, 64:96]
     f32x16 accV2[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};
@@ -373,12 +374,20 @@ static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t
         // per-point variant (no march weights) always runs the latter
         if (p.weights && (p.cfg.flags & TT_R_BWD_PAIR) && !(p.cfg.flags & TT_R_BWD_SOLO))
             tt_launch_bwd_tex2(p, tt_num_cus(), s);
+        else if (p.cfg.stats)
+            hipLaunchKernelGGL((k_decode_bwd_tex<false, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         else
             hipLaunchKernelGGL((k_decode_bwd_tex<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     } else if (p.cfg.flags & TT_R_EXACT_F32) {
-        hipLaunchKernelGGL((k_decode_bwd_tex<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        if (p.cfg.stats)
+            hipLaunchKernelGGL((k_decode_bwd_tex<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((k_decode_bwd_tex<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL((k_decode_bwd_tex<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        if (p.cfg.stats)
+            hipLaunchKernelGGL((k_decode_bwd_tex<false, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((k_decode_bwd_tex<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     }
 }
 

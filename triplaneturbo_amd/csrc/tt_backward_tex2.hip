@@ -114,9 +114,10 @@ __device__ __forceinline__ void split_half(const float (&x)[16], float sc, Frag 
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const float a = x[8 * s + pair_reg<PAIR>(d, 0)] * sc, b = x[8 * s + pair_reg<PAIR>(d, 1)] * sc;
-            const h2_t p = cvt_pk16(a, b);
-            h[d] = __builtin_bit_cast(unsigned, p);
-            l[d] = __builtin_bit_cast(unsigned, cvt_pk16_lo(a - (float)p.x, b - (float)p.y));
+            unsigned ph, pl;
+            split_pair(a, b, ph, pl);
+            h[d] = ph;
+            l[d] = pl;
         }
         f[s].h = __builtin_bit_cast(h8_t, h);
         f[s].l = __builtin_bit_cast(h8_t, l);
@@ -172,8 +173,8 @@ __device__ __forceinline__ void scatter_planes_n(float* __restrict__ grad, unsig
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float x0 = bs[ks][2 * j] * bsc, x1 = bs[ks][2 * j + 1] * bsc;
-                    const h2_t ph = cvt_pk16(x0, x1);
-                    const h2_t pq = cvt_pk16_lo(x0 - (float)ph.x, x1 - (float)ph.y);
+                    h2_t ph, pq;
+                    split_pair(x0, x1, ph, pq);
                     bh[ks][2 * j] = ph.x;
                     bh[ks][2 * j + 1] = ph.y;
                     bl[ks][2 * j] = pq.x;
@@ -446,10 +447,10 @@ __global__ __launch_bounds__(P2_THREADS, 2) void k_decode_bwd_tex2(BwdTexParams 
                     for (int n = 0; n < 2; ++n) {
                         const int smp = 16 * H + 8 * n + js;
                         const float a0 = acc[n][0] * sE, a1 = acc[n][1] * sE, a2 = acc[n][2] * sE, a3 = acc[n][3] * sE;
-                        const h2_t p0 = cvt_pk16(a0, a1), p1 = cvt_pk16(a2, a3);
-                        const u2_t hh2 = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
-                        const u2_t ll2 = {__builtin_bit_cast(unsigned, cvt_pk16_lo(a0 - (float)p0.x, a1 - (float)p0.y)),
-                                          __builtin_bit_cast(unsigned, cvt_pk16_lo(a2 - (float)p1.x, a3 - (float)p1.y))};
+                        unsigned h0, l0, h1, l1;
+                        split_pair(a0, a1, h0, l0);
+                        split_pair(a2, a3, h1, l1);
+                        const u2_t hh2 = {h0, h1}, ll2 = {l0, l1};
                         const int off = (ks * 2 + hh) * P2_BLK + smp * 8 + 4 * piece;
                         *reinterpret_cast<u2_t*>(EFh + off) = hh2;
                         *reinterpret_cast<u2_t*>(EFl + off) = ll2;

@@ -89,6 +89,35 @@ __device__ __forceinline__ h2_t cvt_pk16_lo(float a, float b) {
 __device__ __forceinline__ unsigned cvt_pk16u(float a, float b) { return __builtin_bit_cast(unsigned, cvt_pk16(a, b)); }
 __device__ __forceinline__ unsigned cvt_pk16u_lo(float a, float b) { return __builtin_bit_cast(unsigned, cvt_pk16_lo(a, b)); }
 
+// The split of a PAIR of values: hi = pk_f16(a, b), lo = pk_f16(a - hi.x, b - hi.y) (both residuals exact).
+// TT_SPLIT_PAIR_ASM: one asm block of FOUR instructions -- convert, two v_fma_mix_f32 that subtract the f16 halves of hi
+// straight from the fp32 inputs (a * 1.0 - hi: exact), convert -- where hipcc emits six (convert, v_cvt_f32_f16, subtract,
+// v_cvt_f32_f16_sdwa, subtract, convert).  It also removes the wait states hipcc puts around a lone inline-asm convert
+// (it assumes a dst_sel forwarding hazard for every asm result: +95 s_nop per tile step of the texture backward, which is
+// what the single-instruction asm form of round 4 cost against the truncating builtin).  Bit-identical to the generic form.
+#ifndef TT_SPLIT_PAIR_ASM
+#define TT_SPLIT_PAIR_ASM (TT_SPLIT_MODE == 4)
+#endif
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+#if TT_SPLIT_PAIR_ASM
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mix_f32 %2, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %3, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_pk_f16_f32 %1, %2, %3"
+        : "=&v"(hi), "=v"(lo), "+v"(a), "+v"(b));
+#else
+    const h2_t p = cvt_pk16(a, b);
+    hi = __builtin_bit_cast(unsigned, p);
+    lo = cvt_pk16u_lo(a - (float)p.x, b - (float)p.y);
+#endif
+}
+__device__ __forceinline__ void split_pair(float a, float b, h2_t& hi, h2_t& lo) {
+    unsigned h, l;
+    split_pair(a, b, h, l);
+    hi = __builtin_bit_cast(h2_t, h);
+    lo = __builtin_bit_cast(h2_t, l);
+}
+
 __device__ __forceinline__ void split16(float v, half_t& hi, half_t& lo) {
     const h2_t p = cvt_pk16(v, 0.f);
     hi = p.x;
@@ -182,9 +211,8 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
         for (int j = 0; j < 4; ++j) {
             const f2_t ab = {x[8 * s + 2 * j], x[8 * s + 2 * j + 1]};
             const f2_t as = SCALED ? ab * sc : ab;  // exact (power of two)
-            const h2_t p = cvt_pk16(as.x, as.y);
-            const float ra = as.x - (float)p.x, rb = as.y - (float)p.y;  // exact residuals
-            const h2_t q = cvt_pk16_lo(ra, rb);
+            h2_t p, q;
+            split_pair(as.x, as.y, p, q);
             bh[2 * j] = p.x;
             bh[2 * j + 1] = p.y;
             bl[2 * j] = q.x;
@@ -238,11 +266,7 @@ __device__ __forceinline__ void split16_vec(const float (&x)[N / 2], float sc, S
     for (int t = 0; t < N / 4; ++t) {
         const f2_t ab = {x[pair_reg<PAIR>(t, 0)], x[pair_reg<PAIR>(t, 1)]};
         const f2_t as = ab * sc;  // exact (power of two)
-        const unsigned pu = cvt_pk16u(as.x, as.y);
-        const h2_t p = __builtin_bit_cast(h2_t, pu);
-        const float ra = as.x - (float)p.x, rb = as.y - (float)p.y;  // exact residuals
-        o.h[t] = pu;
-        o.l[t] = cvt_pk16u_lo(ra, rb);
+        split_pair(as.x, as.y, o.h[t], o.l[t]);
     }
 }
 // mv16 on a pre-split operand: y = M x with x = (hi + lo) * un_x
@@ -344,9 +368,8 @@ __device__ __forceinline__ void mv16t(const float* img_f, int col0, const float 
         for (int d = 0; d < 4; ++d) {
             const f2_t ab = {x[8 * s + pair_reg<PAIR_TR>(d, 0)], x[8 * s + pair_reg<PAIR_TR>(d, 1)]};
             const f2_t as = SCALED ? ab * sc : ab;
-            const h2_t p = cvt_pk16(as.x, as.y);
-            const float ra = as.x - (float)p.x, rb = as.y - (float)p.y;
-            const h2_t q = cvt_pk16_lo(ra, rb);
+            h2_t p, q;
+            split_pair(as.x, as.y, p, q);
             bh[2 * d] = p.x;
             bh[2 * d + 1] = p.y;
             bl[2 * d] = q.x;
