@@ -1,6 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_backward.py tests/test_gpu_pair.py tests/test_gpu_forward.py -m gpu -x -q 2>&1 | tail -2
-for r in 1 2 3; do
-bash tools/abn.sh 1 "--steps 100" "--steps 100 --lib-variant oldsplit" 2>&1 | cut -c1-200
-(cd _r3 && bash tools/abn.sh 1 "--steps 100" 2>&1 | cut -c1-200 | sed "s/^/r3 /")
-done
+bash tools/kstats.sh gpurun_out/ks python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras

@@ -16,5 +16,5 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_W
   timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/$out/pmc$i -- $CMD > $R/$out/pmc$i.log 2>&1
   echo "pmc pass $i ($grp) rc=$?"
 done
-timeout 300 python $R/bench.py > $R/$out/bench_n1.json 2> $R/$out/bench_n1.log
+timeout 600 python $R/bench.py > $R/$out/bench_n1.json 2> $R/$out/bench_n1.log
 echo "bench rc=$?"

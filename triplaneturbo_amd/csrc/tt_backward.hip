@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     flush_wgrad_reduced<64, 32>(L, parity, accW1, p.grads.w1, wave_in_blk, lane, 1.f / sA1, 1.f / sU);
     flush_wgrad_reduced<64, 64>(L, parity, accW2, p.grads.w2, wave_in_blk, lane, 1.f / sA2, 1.f / sV);
     atomicAdd(p.grads.w3 + lane, accw3);
+    tile_stats_flush(st);
 }
 
 #ifdef TT_TUNING

@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
         for (int o = 0; o < 3; ++o) atomicAdd(p.grads.v3 + o * 64 + 32 * h2 + i, accV3[h2][o]);
+    tile_stats_flush(st);
 }
 
 static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t s) {

@@ -683,6 +683,7 @@ __global__ __launch_bounds__(P2_THREADS, 2) void k_decode_bwd_tex2(BwdTexParams 
 #pragma unroll
             for (int o = 0; o < 3; ++o) atomicAdd(p.grads.v3 + o * 64 + 32 * H + 16 * a + (lane & 15), accV3[a][o]);
     }
+    tile_stats_flush(st);
 #ifdef TT_TUNING
     P2_PHASE(16);
     if (p.phase_cycles && lane == 0)

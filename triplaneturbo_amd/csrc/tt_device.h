@@ -370,28 +370,39 @@ __device__ __forceinline__ bool gather_tex(const float* __restrict__ planes, int
 }
 
 // Work accounting (tt_render_cfg.stats, measurement only).  NOTHING is kept in registers: the pointer is a kernel argument
-// (wave-uniform), so a production launch (null) pays one scalar branch per counting site, and a measuring launch adds
-// to the counters in memory with one atomic per site and wave.  (Round 4 first kept per-wave counters in registers and
-// flushed them at kernel end: 0.09 ms of the 7.85 ms step -- the decode kernels have no registers to spare.)
+// (wave-uniform), so a production launch (null) pays one scalar branch per counting site; a measuring launch counts in a
+// wave-private LDS slot (one lane, plain read-modify-write) and adds the slot to the caller's counters with three atomics
+// per wave at kernel end.  (Round 4 first kept per-wave counters in registers: 0.09 ms of the 7.85 ms step -- the decode
+// kernels have no registers to spare; then one global atomic per site: free when off, but 15 ms per measuring launch.)
 struct TileStats {
     unsigned long long* p;  // null, or the caller's 4 counters: [0] visited, [1] executed, [2] in-bounds pairs
+    unsigned* w;            // this wave's LDS slot (4 ints) when p != null
 };
 enum { TT_STAT_VISITED = 0, TT_STAT_EXECUTED = 1, TT_STAT_INBOUNDS = 2 };
 __device__ __forceinline__ TileStats tile_stats(uint64_t* stats64) {
-#ifdef TT_NO_STATS  // dev A/B only (tools/build_variants.py): what the counting costs
-    return TileStats{nullptr};
-#else
-    return TileStats{reinterpret_cast<unsigned long long*>(stats64)};
+    TileStats st = {nullptr, nullptr};
+#ifndef TT_NO_STATS  // (dev A/B only, tools/build_variants.py: what the counting costs)
+    __shared__ unsigned tt_stat_slots[16 * 4];  // <= 16 waves per workgroup
+    st.p = reinterpret_cast<unsigned long long*>(stats64);
+    if (st.p) {
+        st.w = tt_stat_slots + 4 * __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        if ((threadIdx.x & 63) < 4) st.w[threadIdx.x & 63] = 0u;
+    }
 #endif
+    return st;
 }
-// wave-uniform `v`; one lane adds
+// wave-uniform `v`; one lane counts
 __device__ __forceinline__ void tile_stat(const TileStats& st, int which, unsigned v = 1) {
     if (st.p) {
-        if ((threadIdx.x & 63) == 0) atomicAdd(st.p + which, (unsigned long long)v);
+        if ((threadIdx.x & 63) == 0) st.w[which] += v;
     }
 }
-__device__ __forceinline__ unsigned long long* tile_stat_ptr(const TileStats& st, int which) {
-    return st.p ? st.p + which : nullptr;
+__device__ __forceinline__ unsigned* tile_stat_ptr(const TileStats& st, int which) { return st.p ? st.w + which : nullptr; }
+__device__ __forceinline__ void tile_stats_flush(const TileStats& st) {
+    if (st.p) {
+        const int l = threadIdx.x & 63;
+        if (l < 3) atomicAdd(st.p + l, (unsigned long long)st.w[l]);
+    }
 }
 
 // ---- coalesced gathers ------------------------------------------------------------------------------------------------
@@ -450,7 +461,7 @@ template <bool NEED_J>
 __device__ __forceinline__ bool gather_geo_c(const float* __restrict__ planes, unsigned tex0, int H, int W, float X,
                                              float Y, float Z, bool valid, float jscale_u, float jscale_v, int lane,
                                              float* T, float (&f)[16], float (&jx)[16], float (&jy)[16],
-                                             float (&jz)[16], unsigned long long* inb = nullptr) {
+                                             float (&jz)[16], unsigned* inb = nullptr) {
     const int i = lane & 31, hi = lane >> 5, js = lane >> 3, c = lane & 7;
     int* Toff = reinterpret_cast<int*>(T);
     float* Tw = T + 32 * 4;
@@ -468,7 +479,7 @@ __device__ __forceinline__ bool gather_geo_c(const float* __restrict__ planes, u
         any = any || cn.any;
         const unsigned long long inmask = __ballot(cn.any);
         if (inb) {
-            if ((threadIdx.x & 63) == 0) atomicAdd(inb, (unsigned long long)__popcll(inmask & 0xffffffffull));
+            if ((threadIdx.x & 63) == 0) *inb += (unsigned)__popcll(inmask & 0xffffffffull);
         }
         if (inmask == 0) continue;  // exact: every contribution of this plane is 0 for the whole tile
         if (hi == 0) {
@@ -573,7 +584,7 @@ __device__ __forceinline__ bool gather_tex_cp(const float* __restrict__ planes, 
 // prompts, and the lane that loads a texel is not the lane that owns the sample: the table holds absolute indices).
 __device__ __forceinline__ bool gather_tex_c(const float* __restrict__ planes, unsigned tex0, int H, int W, float X,
                                              float Y, float Z, bool valid, int lane, float* T, float (&e)[48],
-                                             unsigned long long* inb = nullptr) {
+                                             unsigned* inb = nullptr) {
     const int i = lane & 31, hi = lane >> 5, js = lane >> 3, c = lane & 7;
     int* Toff = reinterpret_cast<int*>(T);
     float* Tw = T + 3 * 32 * 4;
@@ -586,7 +597,7 @@ __device__ __forceinline__ bool gather_tex_c(const float* __restrict__ planes, u
         corners_setup(PLANE_U(p, X, Y, Z), PLANE_V(p, X, Y, Z), H, W, valid, cn);
         const unsigned long long inmask = __ballot(cn.any);
         if (inb) {
-            if ((threadIdx.x & 63) == 0) atomicAdd(inb, (unsigned long long)__popcll(inmask & 0xffffffffull));
+            if ((threadIdx.x & 63) == 0) *inb += (unsigned)__popcll(inmask & 0xffffffffull);
         }
         anyp[p] = inmask != 0;
         any = any || cn.any;
@@ -655,7 +666,7 @@ __device__ __forceinline__ bool gather_geo_bwd_c(const float* __restrict__ plane
                                                  float Y, float Z, bool valid, float sbar, float gux, float guy,
                                                  float guz, float jscale_u, float jscale_v, int lane, float* T,
                                                  float (&f)[16], float (&u)[16], bool (&anyp)[3],
-                                                 unsigned long long* inb = nullptr) {
+                                                 unsigned* inb = nullptr) {
     const int i = lane & 31, hi = lane >> 5, js = lane >> 3, c = lane & 7;
     int* Toff = reinterpret_cast<int*>(T);
     float* Tw = T + 3 * 32 * 4;
@@ -670,7 +681,7 @@ __device__ __forceinline__ bool gather_geo_bwd_c(const float* __restrict__ plane
         geo_corner_coefs(p, H, W, X, Y, Z, valid, sbar, gux, guy, guz, jscale_u, jscale_v, cn, coef);
         const unsigned long long inmask = __ballot(cn.any);
         if (inb) {
-            if ((threadIdx.x & 63) == 0) atomicAdd(inb, (unsigned long long)__popcll(inmask & 0xffffffffull));
+            if ((threadIdx.x & 63) == 0) *inb += (unsigned)__popcll(inmask & 0xffffffffull);
         }
         anyp[p] = inmask != 0;
         any = any || cn.any;

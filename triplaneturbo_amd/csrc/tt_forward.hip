@@ -489,6 +489,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
             }
         }
     }
+    tile_stats_flush(st);
 }
 
 // =====================================================================================================
