@@ -4,7 +4,7 @@ Bars (written here so every test states the same thing):
   * north_star: "gradients matching reference to rtol 1e-4".  The reference is fp32, so the direct comparison is
     HIP vs the fp32 oracle:  ||g_hip - g_32|| / ||g_32|| <= TOL_VS_FP32 = 1e-4 for d/d planes and the six matrices.
   * fp64 arbiter: the HIP result must also be as close to the exact (fp64) math as the fp32 oracle is (x3 slack for
-    summation order / atomics), or within 1e-4 of it.
+    summation order / atomics), or within 1e-4 of it.  (Fuzzed, ill-conditioned scenes: see COND32 below.)
   * SURVEY 8(d), element-wise: |a - b| <= RTOL_ELEM |b| + ATOL_ELEM max|b| with RTOL_ELEM = 1e-4, ATOL_ELEM = 1e-6.
     Two fp32 evaluations of these gradients that differ only in summation order do NOT meet that bar on every element
     (the fp32 oracle itself misses it against fp64 on a sizeable fraction of the elements: inv_std = 100 amplifies the
@@ -31,9 +31,20 @@ ELEM_VS_FP32 = 0.04  # and directly against the fp32 oracle at most 4 % of the e
 #                      bar against fp64 on 5 ... 97 % of the elements with worst elements 100 ... 18 000x their allowance.
 ELEM_VS_FP32_EXTREME = 0.08  # the one test with weight matrices scaled by 3e5 / 2e-6 / 7e4 (test_weight_matrices_of_any_scale:
 #                      measured 6.3 %, worst element 11x): the fp32 oracle's own intermediate values lose bits there
-NOISE32_CAP = 0.3   # fuzzed, ill-conditioned scenes: the HIP-vs-fp32 bar may widen to at most 0.3 x the fp32 oracle's
-#                      own distance from fp64 (measured on fuzz seed 5, the only such case: 0.23 ... 0.26), and only where the exact_f32 kernels on the SAME inputs are as far from the
-#                      fp32 oracle (tests/test_gpu_fuzz.py records both): then it is the scene, not the operand split
+# Fuzzed scenes (tests/test_gpu_fuzz.py; 400 seeds, profiles/r04_fuzz_400.txt) include ILL-CONDITIONED ones: the fp32 oracle
+# itself is 1e-4 ... 1e-2 from fp64 (NeuS alpha = a ratio of nearly equal sigmoids: rounding of the sdf is amplified by
+# inv_std x cancellation).  There a different fp32 evaluation order gives a different fp32 answer: the exact_f32 kernels --
+# plain fp32 MFMA arithmetic, no operand split -- sit 3.1e-4 from the fp32 oracle in seed 391 where that oracle is 1.5e-4 from
+# fp64, and 1.6e-4 / 1.2e-4 in seeds 198 / 229; where they replay the oracle's operation order closely they sit 4e-6 from it
+# while the split-fp16 path, just as close to fp64 as the oracle is (ratio 0.9 ... 1.33 over all 400 seeds), is up to 1.9x
+# the oracle's own error away from it (seed 288).  So "HIP vs fp32 oracle <= 1e-4" cannot be asked of ANY fp32-grade
+# implementation there; what can: a case may exceed it only if (i) the fp32 oracle is further than COND32 from fp64 for
+# that gradient and (ii) the HIP gradient is at most COND_K x as far from fp64 as the fp32 oracle is.  Round 3 / early round 4
+# used a fraction of the oracle's error (noise32 <= 0.5 / 0.3) plus an exact_f32 twin that had to be "equally far": the 400
+# seeds show that criterion wrong in both directions, the twin is still recorded for information.
+COND32 = 3e-5
+COND_K = 2.0
+KINK_TAU = 2.0 ** -19  # see kink_free_rays
 NAMES = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]
 
 
@@ -62,12 +73,11 @@ def report(case, rows):
         pass
 
 
-def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-4, elem=True, noise32=0.0,
+def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-4, elem=True, cond_aware=False,
                 elem_vs_fp32=ELEM_VS_FP32):
-    """g_*: lists of tensors (HIP, fp32 oracle, fp64 oracle) in the order of `names`.  noise32 > 0 (fuzzed, possibly
-    ill-conditioned scenes only): the direct HIP-vs-fp32 bar is widened to noise32 x the fp32 oracle's own distance from
-    fp64 where that is larger -- two fp32 evaluations cannot agree better than either agrees with the exact result."""
-    assert noise32 <= NOISE32_CAP
+    """g_*: lists of tensors (HIP, fp32 oracle, fp64 oracle) in the order of `names`.  cond_aware (fuzzed, possibly
+    ill-conditioned scenes only): a gradient whose fp32 oracle is itself further than COND32 from fp64 may exceed the direct
+    HIP-vs-fp32 bar, but must then be within COND_K x the fp32 oracle's own distance from fp64 (see COND32 above)."""
     rows = {}
     for n, a, b32, b64 in zip(names, g_hip, g32, g64):
         rows[n] = {"hip_vs_fp32": rel(a, b32), "hip_vs_fp64": rel(a, b64), "fp32_vs_fp64": rel(b32, b64),
@@ -75,13 +85,41 @@ def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-
                    "elem_fp32_vs_fp64": elementwise(b32, b64)}
     report(case, rows)
     for n, r in rows.items():
-        assert r["hip_vs_fp32"] <= max(tol32, noise32 * r["fp32_vs_fp64"]), (case, n, rows)
+        if r["hip_vs_fp32"] > tol32:
+            assert cond_aware and r["fp32_vs_fp64"] > COND32, (case, n, rows)
+            assert r["hip_vs_fp64"] <= COND_K * r["fp32_vs_fp64"], (case, n, rows)
+            assert r["hip_vs_fp32"] <= (1.0 + COND_K) * r["fp32_vs_fp64"], (case, n, rows)  # (implied; kept explicit)
         assert r["hip_vs_fp64"] <= max(tol64, 3 * r["fp32_vs_fp64"]), (case, n, rows)
         if elem:
             assert r["elem_hip_vs_fp64"]["viol_frac"] <= ELEM_SLACK * r["elem_fp32_vs_fp64"]["viol_frac"] + ELEM_FLOOR, \
                 (case, n, r)
             assert r["elem_hip_vs_fp32"]["viol_frac"] <= elem_vs_fp32, (case, n, r)
     return rows
+
+
+def kink_free_rays(cache, sdf_weights, feat_weights, ro, rd, ts, te, n_view, tau=KINK_TAU):
+    """Rays none of whose samples sits on a ReLU kink of the sdf network.  The normal n = d sdf / d x of a ReLU network
+    jumps by a finite amount where a hidden pre-activation crosses zero; a sample whose (fp64) pre-activation is within
+    rounding distance of zero -- |h| < tau * sum_k |w_k x_k|, tau = 2^-19 = 8x the 2^-22 of a split-fp16 product, 32x fp32's
+    2^-24 -- has no well-defined fp32-grade normal: which side an implementation lands on depends on its summation order
+    (the reference's CUDA kernels included).  In a 20-ray fuzz scene ONE such sample moves every gradient by 1e-3 (seed 99:
+    one sample of 3 600, pre-activation at 2.0e-7 of its scale, all other samples within 3e-6; at 65 536 rays the same
+    flip is 1e-6 of the gradient), so the fuzz takes rays with such a sample out of the loss.  Returns a bool (n_rays,)."""
+    from oracle import cpu_ref as O
+    with torch.no_grad():
+        tm = ((ts + te) * 0.5).double()
+        B = cache.shape[0] * n_view
+        pts = (ro.reshape(-1, 1, 3).double() + rd.reshape(-1, 1, 3).double() * tm[..., None]).reshape(B, -1, 3)
+        og = O.geometry_forward(pts, cache.double().repeat_interleave(n_view, 0), [w.double() for w in sdf_weights],
+                                [w.double() for w in feat_weights], output_normal=False)
+        x = og["enc_geo"]
+        near = torch.zeros(x.shape[0], dtype=torch.bool)
+        for w in sdf_weights[:-1]:
+            w = w.double()
+            h, scale = x @ w.T, x.abs() @ w.abs().T
+            near |= ((h.abs() < tau * scale) & (scale > 0)).any(dim=1)
+            x = torch.relu(h)
+        return ~near.reshape(ts.shape[0], -1).any(dim=1)
 
 
 def check_outputs(case, out_hip, o32, o64, keys, slack=4.0, floor=2e-5):

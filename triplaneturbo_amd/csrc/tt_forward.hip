@@ -445,6 +445,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
         if (b >= tg.n_blocks) continue;  // padding of the ragged last deal round
         bool ray_ok;
         const long long ray = tile_ray(tg, b, i, ray_ok);
+        const float ray_okf = tt_opaque(ray_ok ? 1.f : 0.f);  // 0/1 factor the compiler cannot fold back into a mask
         const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
         const int view = (int)(ray / cfg.rays_per_view);
         DecodeCfg dc;
@@ -464,7 +465,9 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
 #pragma nounroll
         for (int sb0 = ck * tg.chunk; sb0 < s_end; sb0 += tg.sb) {
             const int si = sb0 + ks;
-            const bool rvalid = ray_ok && si < s_end;
+            // validity as a product of 0/1 factors tested ONCE (no select on a lane mask the scalar ALU has just combined:
+            // tools/mask_hazard_lint.py)
+            const bool rvalid = ray_okf * (si < s_end ? 1.f : 0.f) != 0.f;
             tile_stat(st, TT_STAT_VISITED);
             const long long sidx = ray * S + (si < S ? si : S - 1);
             const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
