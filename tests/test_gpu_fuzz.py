@@ -86,7 +86,7 @@ def test_random_configuration_matches_oracle(mods, seed):
         assert float(g_hip[i].abs().max()) == 0.0, (case, names[i])
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(N_SEEDS // 2))
 def test_random_point_query_matches_oracle(seed):
     """geometry.forward on random point clouds (inside and outside the box), random prompt / view / plane sizes:
     outputs, d/d planes, d/d weights and d/d points (second order through sdf_grad / normal) against the oracle."""
@@ -133,10 +133,11 @@ def test_random_point_query_matches_oracle(seed):
     names = ["points", "planes", "w1", "w2", "w3", "v1", "v2", "v3"]
     nz = [i for i, t in enumerate(g64) if float(t.abs().max()) > 0]
     check_grads(case, [g_hip[i].cpu().reshape(g64[i].shape) for i in nz], [g32[i] for i in nz], [g64[i] for i in nz],
-                names=[names[i] for i in nz], elem=False)  # no widened bar: every case sits < 5e-5 from the fp32 oracle
+                names=[names[i] for i in nz], elem=False, cond_aware=True)  # (200 seeds: one case, points[136], where the fp32
+    #                ORACLE is the outlier -- 1.5e-3 from fp64 in d/d V1 with the HIP gradient 1.9e-6 from fp64; all others < 5e-5)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(N_SEEDS // 2))
 def test_random_eval_render_equals_training_forward(seed):
     """The fused eval kernel with both thresholds at 0 against the training forward kernels on random configurations
     (two different work decompositions of the same arithmetic: ray tiles walked front to back vs (ray block, chunk) items)."""
