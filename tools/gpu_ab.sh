@@ -1,2 +1,6 @@
 cd $GRAFT_REPO_ROOT
-TT_FUZZ_SEEDS=400 timeout 1700 python -m pytest tests/test_gpu_fuzz.py -m gpu -q --tb=line -k "point_query or eval_render" 2>&1 | grep -v "^$" | cut -c1-700 | tail -25
+for r in 1 2; do
+bash tools/abn.sh 1 "--steps 100" 2>&1 | cut -c1-200
+(cd _r3 && bash tools/abn.sh 1 "--steps 100" 2>&1 | cut -c1-200 | sed "s/^/r3 /")
+done
+timeout 900 python -m pytest tests/test_gpu_backward.py tests/test_gpu_pair.py tests/test_gpu_points.py -m gpu -x -q 2>&1 | tail -2

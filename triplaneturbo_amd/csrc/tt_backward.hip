@@ -178,11 +178,13 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             TT_PHASE(1);
             if (!any) continue;  // exact: no in-bounds texel => f = J = 0, every mask false
             tile_stat(st, TT_STAT_EXECUTED);
-            float h1[32], h2[32], a2[32], a1[32], q[16];
-            mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
+            // h1, h2 (and a1 under WG16) stay in RAW form: accumulators + a per-lane power-of-two factor (tt_mfma16.h,
+            // "deferred factors"); their consumers are signs, the next product, and fmas that take the factor on the scalar
+            float h1[32], h2[32], a2[32], a1[32], q[16], u1, u2;
+            mvx<EXACT, 64, 32, true>(L + OFF_W1, f, h1, i, hi, 1.f, &u1);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mvx<EXACT, 64, 64>(L + OFF_W2, h1, h2, i, hi);
+            mvx<EXACT, 64, 64, true>(L + OFF_W2, h1, h2, i, hi, u1, &u2);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
 #pragma unroll
@@ -193,10 +195,11 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             }
             // a2 and a1 feed a product AND an outer product (dW2, dW1): split once under the per-launch scales
             Split16<64, GEO_PAIR> a2s, a1s;  // (consumed by the transposed products and the outer-product staging)
+            float ua1 = 1.f;                 // factor of a1 where it is RAW
             if (WG16) {
                 split16_vec<64, GEO_PAIR>(a2, sA2, a2s);
 #if TT_BWD_WT_COPIES
-                mv16_pre<64, 64>(L + GOFF_W2T, a2s, 1.f / sA2, a1, i, hi);
+                mv16_pre<64, 64, true>(L + GOFF_W2T, a2s, 1.f / sA2, a1, i, hi, &ua1);
 #else
                 mv16t_pre<64, 64, 64>(L + OFF_W2, 0, a2s, 1.f / sA2, a1, lane);
 #endif
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
             if (WG16) {
-                split16_vec<64, GEO_PAIR>(a1, sA1, a1s);
+                split16_vec<64, GEO_PAIR>(a1, sA1 * ua1, a1s);
 #if TT_BWD_WT_COPIES
                 mv16_pre<32, 64>(L + GOFF_W1T, a1s, 1.f / sA1, q, i, hi);
 #else
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 for (int r = 0; r < 32; ++r) t1[r] = h1[r] > 0.f ? t1[r] : 0.f;  // b1bar
                 float v[32];
 #pragma unroll
-                for (int r = 0; r < 32; ++r) v[r] = fmaf(sbar, h1[r], t1[r]);
+                for (int r = 0; r < 32; ++r) v[r] = fmaf(sbar * u1, h1[r], t1[r]);
                 TT_PHASE(4);
                 // dW2 += a2 v^T
                 if (do_wgrad) {
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 float t2[32];
                 mvx<EXACT, 64, 64>(L + OFF_W2, t1, t2, i, hi);
 #pragma unroll
-                for (int r = 0; r < 32; ++r) t2[r] = fmaf(sbar, h2[r], h2[r] > 0.f ? t2[r] : 0.f);
+                for (int r = 0; r < 32; ++r) t2[r] = fmaf(sbar * u2, h2[r], h2[r] > 0.f ? t2[r] : 0.f);
                 stage_rows<64>(Xs, t2, i, hi);
                 accw3 += rowsum32(Xs, lane);
                 TT_PHASE(5);

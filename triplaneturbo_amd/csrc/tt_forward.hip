@@ -157,15 +157,17 @@ __device__ __forceinline__ void decode_tex_fwd(const float* L, const DecodeCfg& 
         for (int r = 0; r < 48; ++r) t += e[r];
         c[0] = c[1] = c[2] = t;
     } else if (__any(any)) {  // exact skip: e == 0 for the whole tile => features == 0 (bias-free MLP)
-        float k1[32], k2[32];
-        mvx<EXACT, 64, 96>(L + OFF_V1, e, k1, i, hi);
+        // hidden vectors stay in RAW form (accumulators + a per-lane power-of-two factor, tt_mfma16.h): ReLU and the next
+        // product's normalisation do not care, the factor is applied once to the three outputs
+        float k1[32], k2[32], u1, u2;
+        mvx<EXACT, 64, 96, true>(L + OFF_V1, e, k1, i, hi, 1.f, &u1);
 #pragma unroll
         for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
-        mvx<EXACT, 64, 64>(L + OFF_V2, k1, k2, i, hi);
+        mvx<EXACT, 64, 64, true>(L + OFF_V2, k1, k2, i, hi, u1, &u2);
 #pragma unroll
         for (int r = 0; r < 32; ++r) k2[r] = fmaxf(k2[r], 0.f);
 #pragma unroll
-        for (int o = 0; o < 3; ++o) c[o] = dot_lds<64>(L + OFF_V3 + 64 * o, k2, hi);
+        for (int o = 0; o < 3; ++o) c[o] = dot_lds<64>(L + OFF_V3 + 64 * o, k2, hi) * u2;
     }
 }
 
@@ -193,14 +195,14 @@ __device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& 
         gq[2] = tz;
     } else if (__any(any)) {
         tile_stat(dc.st, TT_STAT_EXECUTED);
-        float h1[32], h2[32];
-        mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
+        float h1[32], h2[32], u1, u2;  // RAW hidden vectors (see decode_tex_fwd): only their signs and the dot product matter
+        mvx<EXACT, 64, 32, true>(L + OFF_W1, f, h1, i, hi, 1.f, &u1);
 #pragma unroll
         for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-        mvx<EXACT, 64, 64>(L + OFF_W2, h1, h2, i, hi);
+        mvx<EXACT, 64, 64, true>(L + OFF_W2, h1, h2, i, hi, u1, &u2);
 #pragma unroll
         for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
-        s0 = dot_lds<64>(L + OFF_W3, h2, hi);
+        s0 = dot_lds<64>(L + OFF_W3, h2, hi) * u2;
         if (NEED_N) {
             // reverse-mode input gradient: a2 = m2 . w3 ; a1 = m1 . (W2^T a2) ; q = W1^T a1
             float a2[32], a1[32], q[16];
@@ -210,10 +212,11 @@ __device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& 
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
             }
-            mvtx<EXACT, 64, 64, 64>(L + OFF_W2, 0, a2, a1, i, hi);
+            float ua1;
+            mvtx<EXACT, 64, 64, 64, true>(L + OFF_W2, 0, a2, a1, i, hi, 1.f, &ua1);
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-            mvtx<EXACT, 32, 64, 32>(L + OFF_W1, 0, a1, q, i, hi);
+            mvtx<EXACT, 32, 64, 32>(L + OFF_W1, 0, a1, q, i, hi, ua1);
             float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

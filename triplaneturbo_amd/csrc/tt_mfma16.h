@@ -181,9 +181,16 @@ __device__ __forceinline__ void stage_image16(float* dst_f, const float* __restr
 // that brings its largest |x| into [2^14, 2^15) and the result is scaled back -- exact, and it makes the product
 // independent of the magnitude of x (gradient chains carry values of 1e-10 that fp16 cannot hold; columns of a
 // mat-vec are independent, so each gets its own exponent).
-template <int NOUT, int NIN, bool SCALED = true>
+//
+// DEFERRED FACTORS (RAW): every scale in this scheme is a power of two, so "multiply the accumulators back" commutes exactly
+// with everything a hidden vector goes through before it is consumed (ReLU, masks by sign, the next product's
+// normalisation).  With RAW the product returns the accumulators as they are plus the per-lane factor `*yf` (true value =
+// y * yf); the next product takes that factor as `xf`: its per-sample exponent search runs on the raw values (same operand
+// bits as on the true ones) and xf goes into ITS result factor.  One multiply per hidden value and layer less, bit-identical
+// results.
+template <int NOUT, int NIN, bool SCALED = true, bool RAW = false>
 __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i,
-                                     int hi) {
+                                     int hi, float xf = 1.f, float* yf = nullptr) {
     constexpr int MT = NOUT / 32, KS = NIN / 16, RS = 2 * NIN + 8;
     const half_t* row = reinterpret_cast<const half_t*>(img_f) + (size_t)i * RS + 8 * hi;
     const float wun = img_f[(size_t)i * (NIN + 4) + NIN];  // inverse of the matrix normalisation (stage_image16)
@@ -198,6 +205,7 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
         sc = __builtin_bit_cast(float, (unsigned)(268 - E) << 23);       // 2^(141 - E): max |x| -> [2^14, 2^15)
         un = wun * __builtin_bit_cast(float, (unsigned)(E - 14) << 23);  // 1 / sc
     }
+    un *= xf;
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -234,10 +242,11 @@ __device__ __forceinline__ void mv16(const float* img_f, const float (&x)[NIN / 
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
     }
+    if (RAW) *yf = un;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k] * un;
+        for (int k = 0; k < 16; ++k) y[16 * m + k] = RAW ? acc[m][k] : acc[m][k] * un;
 }
 
 // ---- operands split ONCE per vector, with a scale known before the launch --------------------------------------------
@@ -270,9 +279,9 @@ __device__ __forceinline__ void split16_vec(const float (&x)[N / 2], float sc, S
     }
 }
 // mv16 on a pre-split operand: y = M x with x = (hi + lo) * un_x
-template <int NOUT, int NIN>
+template <int NOUT, int NIN, bool RAW = false>
 __device__ __forceinline__ void mv16_pre(const float* img_f, const Split16<NIN, PAIR_SEQ>& x, float un_x,
-                                         float (&y)[NOUT / 2], int i, int hi) {
+                                         float (&y)[NOUT / 2], int i, int hi, float* yf = nullptr) {
     constexpr int MT = NOUT / 32, KS = NIN / 16, RS = 2 * NIN + 8;
     const half_t* row = reinterpret_cast<const half_t*>(img_f) + (size_t)i * RS + 8 * hi;
     const float un = img_f[(size_t)i * (NIN + 4) + NIN] * un_x;
@@ -299,10 +308,11 @@ __device__ __forceinline__ void mv16_pre(const float* img_f, const Split16<NIN, 
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
     }
+    if (RAW) *yf = un;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k] * un;
+        for (int k = 0; k < 16; ++k) y[16 * m + k] = RAW ? acc[m][k] : acc[m][k] * un;
 }
 
 // ---- TRANSPOSED products from the forward image: y = M^T x without a second (transposed) image ----------------------------
@@ -339,9 +349,9 @@ __device__ __forceinline__ h8_t tr_frag(const lds_sv4_t* base, int ks, int m, in
 }
 
 // y[NOUT] = M[NIN][col0 .. col0 + NOUT)^T x[NIN]; img_f = forward image of M (NIN rows, KM columns)
-template <int NOUT, int NIN, int KM, bool SCALED = true>
+template <int NOUT, int NIN, int KM, bool SCALED = true, bool RAW = false>
 __device__ __forceinline__ void mv16t(const float* img_f, int col0, const float (&x)[NIN / 2], float (&y)[NOUT / 2],
-                                      int lane) {
+                                      int lane, float xf = 1.f, float* yf = nullptr) {
     constexpr int MT = NOUT / 32, KS = NIN / 16;
     const lds_sv4_t* base = tr_lane_base<KM>(img_f, col0, lane);
     const float wun = img_f[KM];  // inverse of the matrix normalisation (the same in the pad of every row)
@@ -356,6 +366,7 @@ __device__ __forceinline__ void mv16t(const float* img_f, int col0, const float 
         sc = __builtin_bit_cast(float, (unsigned)(268 - E) << 23);
         un = wun * __builtin_bit_cast(float, (unsigned)(E - 14) << 23);
     }
+    un *= xf;
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -388,10 +399,11 @@ __device__ __forceinline__ void mv16t(const float* img_f, int col0, const float 
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
     }
+    if (RAW) *yf = un;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) y[16 * m + k] = acc[m][k] * un;
+        for (int k = 0; k < 16; ++k) y[16 * m + k] = RAW ? acc[m][k] : acc[m][k] * un;
 }
 // the same on an operand already split in PAIR_TR order (x = (hi + lo) * un_x)
 template <int NOUT, int NIN, int KM>
@@ -452,32 +464,38 @@ __device__ __forceinline__ void stage_weights_t(float* dst_f, const float* __res
 }
 
 // y[NOUT] = M[NOUT][NIN] x
-template <bool EXACT, int NOUT, int NIN>
-__device__ __forceinline__ void mvx(const float* img, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i, int hi) {
+// RAW (deferred factors, see mv16): y comes back unscaled with its per-lane factor in *yf, x may carry a factor xf.  The
+// fp32 path has no factors: it returns true values and *yf = 1 (callers pass 1 on as xf).
+template <bool EXACT, int NOUT, int NIN, bool RAW = false>
+__device__ __forceinline__ void mvx(const float* img, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i, int hi,
+                                    float xf = 1.f, float* yf = nullptr) {
     if constexpr (EXACT) {
         mv_fwd<NOUT, NIN>(img, x, y, i, hi);
+        if (RAW) *yf = 1.f;
     } else {
-        mv16<NOUT, NIN>(img, x, y, i, hi);
+        mv16<NOUT, NIN, true, RAW>(img, x, y, i, hi, xf, yf);
     }
 }
 // y[NOUT] = M^T x with `img_t` the split-fp16 image of M^T (stage_weights_t) and `img` the fp32 image of M (EXACT)
-template <bool EXACT, int NOUT, int NIN, int KM>
+template <bool EXACT, int NOUT, int NIN, int KM, bool RAW = false>
 __device__ __forceinline__ void mvtx_copy(const float* img_t, const float* img, const float (&x)[NIN / 2],
-                                          float (&y)[NOUT / 2], int i, int hi) {
+                                          float (&y)[NOUT / 2], int i, int hi, float xf = 1.f, float* yf = nullptr) {
     if constexpr (EXACT) {
         mv_bwd<NOUT, NIN, KM + 4>(img, x, y, i, hi);
+        if (RAW) *yf = 1.f;
     } else {
-        mv16<NOUT, NIN>(img_t, x, y, i, hi);
+        mv16<NOUT, NIN, true, RAW>(img_t, x, y, i, hi, xf, yf);
     }
 }
 // y[NOUT] = M[:, col0 .. col0 + NOUT)^T x for M (NIN rows, KM columns) staged by stage_weights at `img`: from the fp32
 // image by strided column reads (EXACT), from the split-fp16 image by transposed reads (mv16t)
-template <bool EXACT, int NOUT, int NIN, int KM>
+template <bool EXACT, int NOUT, int NIN, int KM, bool RAW = false>
 __device__ __forceinline__ void mvtx(const float* img, int col0, const float (&x)[NIN / 2], float (&y)[NOUT / 2], int i,
-                                     int hi) {
+                                     int hi, float xf = 1.f, float* yf = nullptr) {
     if constexpr (EXACT) {
         mv_bwd<NOUT, NIN, KM + 4>(img + col0, x, y, i, hi);
+        if (RAW) *yf = 1.f;
     } else {
-        mv16t<NOUT, NIN, KM>(img, col0, x, y, 32 * hi + i);
+        mv16t<NOUT, NIN, KM, true, RAW>(img, col0, x, y, 32 * hi + i, xf, yf);
     }
 }
