@@ -23,7 +23,7 @@
 // variant stay on k_decode_bwd_tex.
 //
 // STATUS (round 4, profiles/experiments/README.md "Round 4"): CORRECT -- every gradient within 1e-6 of the one-wave kernel
-// (tests/test_gpu_pair.py) -- but SLOWER: 4.31 ms against 2.93 ms on configs[1], so it is opt-in (TT_R_BWD_PAIR) and the
+// (tests/test_gpu_pair.py) -- but SLOWER: 4.07 ms against 2.87 ms on configs[1] (4.31 / 2.93 when first built), so it is opt-in (TT_R_BWD_PAIR) and the
 // default stays k_decode_bwd_tex.  Measured causes: the code around the accumulators needs ~245 registers (gather
 // coefficients, scatter lists, fragment addressing), so at the 168-register cap of 3 waves / SIMD ~70 values live in
 // scratch and the accumulators are reloaded around the scatter; and a pair hand-off costs ~740 cycles of flag ping-pong
