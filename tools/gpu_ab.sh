@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-bash tools/abn.sh 1 "--steps 50" "--steps 50 --bwd-pair" 2>&1 | cut -c1-160
+python tools/profile_kernels.py 10 0 0x2000 0x100 0 0x2000 2>&1 | tail -5

@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     // tt_planes_unpack_grad.  Spreads same-texel atomics (which serialise at the memory side) over n_copies addresses.
     float* const grad_out =
         p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
-    const unsigned grad_bytes = (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
+    // (tuning build, TT_DBG_NO_ATOMICS: num_records = 0 -- every flush atomic is still issued and then dropped by the range check)
+    const unsigned grad_bytes =
+        TT_DBG(cfg.flags, TT_DBG_NO_ATOMICS) ? 0u : (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
 
     const TileStats st = STATS ? tile_stats(cfg.stats) : TileStats{nullptr};
     f32x16 accW1[2][1] = {{ZERO16}, {ZERO16}};

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     const float shrink = cfg.rgb_grad_shrink;
     float* const grad_out =  // private copy of the gradient planes of this workgroup (see k_decode_bwd_geo)
         p.grad_packed + (size_t)(blockIdx.x % (unsigned)p.n_copies) * cfg.n_prompts * plane_stride;
-    const unsigned grad_bytes = (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
+    // (tuning build, TT_DBG_NO_ATOMICS: num_records = 0 -- every flush atomic is still issued and then dropped by the range check)
+    const unsigned grad_bytes =
+        TT_DBG(cfg.flags, TT_DBG_NO_ATOMICS) ? 0u : (unsigned)(cfg.n_prompts * plane_stride * sizeof(float));  // one copy, < 4 GB - 256
 
     const TileStats st = STATS ? tile_stats(cfg.stats) : TileStats{nullptr};
     f32x16 accV1a[2][2] = {{ZERO16, ZERO16}, {ZERO16, ZERO16}};  // dV1[:, 0:64]

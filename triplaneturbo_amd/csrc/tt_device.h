@@ -35,6 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TT_DBG_NO_GATHER 0x400
 #define TT_DBG_NO_MLP 0x800
 #define TT_DBG_NO_STORE 0x1000
+#define TT_DBG_NO_ATOMICS 0x2000 /* plane-gradient flush atomics issued but dropped (buffer range check) */
 // (0x2000 no combine, 0x4000 no global atomics, 0x8000 no scatter MFMA, 0x10000 no claims: ablations of the
 // pre-pipelining scatter, results in profiles/r02_ablations.txt; the straight-line scatter_planes has no switches)
 
