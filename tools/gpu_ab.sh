@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python tools/profile_kernels.py 10 0 0x2000 0x100 0 0x2000 2>&1 | tail -5
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+bash tools/abn.sh 1 "--steps 100" 2>&1 | cut -c1-170
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -2

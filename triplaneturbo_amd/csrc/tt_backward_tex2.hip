@@ -52,15 +52,13 @@
 #define P2_REGION (P2_FRAGS > 2 * P2_SCAT_FLOATS ? P2_FRAGS : 2 * P2_SCAT_FLOATS)
 #define P2_CTRL P2_REGION                 /* 16 ints: flags[2], any[2], item b (2), ck, ok; then cbar[2 waves][3][32] */
 #define P2_ES2 (P2_CTRL + 16 + 2 * 96)    /* Q rows of plane 2 (the wave whose turn it is): [32 samples][33] */
-#ifdef P2_EXP_TINY
-#define P2_PAIR_FLOATS 2048
-#else
 #define P2_PAIR_FLOATS (P2_ES2 + 32 * 33 + 8)
-#endif
 static_assert(SCATTER_M_FLOATS + 32 * 33 + 2 * 32 * 4 + SCATTER_TAG_INTS <= P2_SCAT_FLOATS, "scatter region too small");
 static_assert(3 * 32 * 8 <= P2_XF_HALFS, "gather tables must fit XF1");
 static_assert(16 * XS <= 4 * P2_BLK / 2, "the dV3 window (16 rows) must fit my own blocks of XF1");
 
+// (P2_DBG_NO_SCATTER / P2_DBG_NO_OUTER / P2_DBG_NO_ATOMICS: compile-time ablations behind the numbers of
+// profiles/experiments/README.md, tools/build_variants.py; never defined in the product build)
 // tuning build only: cycles per phase summed over waves into p.phase_cycles[0..19] (tools/phase_cycles_pair.py)
 #ifdef TT_TUNING
 #define P2_PHASE(k)                                                    \
