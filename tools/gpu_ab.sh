@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-bash tools/abn.sh 1 "--steps 100" 2>&1 | cut -c1-170
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+bash tools/abn.sh 2 "--steps 100" "--steps 100 --lib-variant r1" "--steps 100 --lib-variant r3" "--steps 100 --lib-variant r4" "--steps 100 --lib-variant r5" 2>&1 | cut -c1-170
