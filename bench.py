@@ -66,13 +66,30 @@ BYTES_MARCH_FWD = 44        # t_starts, t_ends, sdf, sdf_grad(3), features(3) re
 BYTES_MARCH_BWD = 68        # the 9 above + trans + g_sdf_grad(3) read; (d sdf, d sdf_grad) float4 written
 PEAK_F32_TFLOPS = 157.3     # dense fp32-input MFMA = fp32 vector peak (MI355X_MICROARCH.md): SURVEY 8(d)'s MLP roofline
 PEAK_F16_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
-PEAK = {"f32": PEAK_F32_TFLOPS, "valu": PEAK_F32_TFLOPS, "f16x3": PEAK_F16_TFLOPS / 3.0, "f16x4": PEAK_F16_TFLOPS / 4.0}
+PEAK = {"f32": PEAK_F32_TFLOPS, "valu": PEAK_F32_TFLOPS, "f16x3": PEAK_F16_TFLOPS / 3.0, "f16x4": PEAK_F16_TFLOPS / 4.0,
+        "f16x6": PEAK_F16_TFLOPS / 6.0}
 PEAK_HBM_GBS = 8000.0
-DTYPE = "f32 (2xfp16-split products, RNE split: ~24-bit)"
-DTYPE_EXACT = "f32 (fp32-input MFMA)"
+# precision modes of the MLP products (include/tt_abi.h): the arithmetic type the path computes in
+DTYPES = {
+    "split3": "f32 (fp32-grade: exact 3-piece fp16 operand split, 6 x v_mfma_f32_32x32x16_f16 per k-step, fp32 accumulation)",
+    "f32": "f32 (fp32-input MFMA, v_mfma_f32_32x32x2_f32)",
+    "split2": "f32 storage / accumulation, FAST products (2-piece fp16 split, 3 MFMA terms: ~2^-21.5 per product)",
+}
+DTYPE_NOTES = {
+    "split3": "fp32 storage, accumulation and element-wise math; every mat-vec product of the MLP chains with both operands "
+              "split EXACTLY in three fp16 pieces (hi + mid + lo = v, round-to-nearest-even, operands normalised to the top of "
+              "the fp16 range) and the six product terms above 2^-33 accumulated in fp32 on the fp16 matrix pipe: product error "
+              "<= 2^-24 of sum |a b| (profiles/r05_split3_probe.txt), the class of the reference's fp32 GEMM "
+              "(networks.py:91-97).  Reductions over samples (weight-gradient outer products, scatter-combine GEMM) use "
+              "2-piece operands with all four cross terms (DESIGN.md section 3).  `modes` below: the same build on the "
+              "fp32-input MFMA and in the 2-piece fast mode",
+    "f32": "TT_R_EXACT_F32: every matrix product on v_mfma_f32_32x32x2_f32",
+    "split2": "TT_R_SPLIT2, the fast mode (the default of rounds 2-4): 2-piece operands, 3 x v_mfma_f32_32x32x16_f16 per "
+              "k-step, ~2^-21.5 per product -- a tolerance-bounded approximation of the reference's fp32 products",
+}
 
 
-def kernel_roofline(name, ms, n_samples, exact, wgrad_f32=False, work=None):
+def kernel_roofline(name, ms, n_samples, prec, wgrad_f32=False, work=None):
     """Both forms of  max(algorithmic bytes / HBM peak, algorithmic FLOP / MFMA peak) / measured time :
       frac_8d       SURVEY 8(d) literally: bytes_8d / 8 TB/s against ALL algorithmic FLOP / 157.3 TFLOP/s (the fp32-MFMA
                     roofline 8(d) names).  A value > 1 means the kernel beats both 8(d) ceilings -- possible because the
@@ -80,9 +97,11 @@ def kernel_roofline(name, ms, n_samples, exact, wgrad_f32=False, work=None):
       frac_pipe_mix the same with every FLOP priced on the pipe that executes it (split-fp16 products: 2500/3 TFLOP/s).
     """
     a = ALG[name]
-    macs = {"f16x3": 0, "f16x4": 0, "f32": 0, "valu": 0, **a["macs"]}
-    if exact:  # every matrix product on the fp32 MFMA
+    macs = {"f16x3": 0, "f16x4": 0, "f16x6": 0, "f32": 0, "valu": 0, **a["macs"]}
+    if prec is True or prec == "f32":  # every matrix product on the fp32 MFMA
         macs = {"f16x3": 0, "f16x4": 0, "f32": macs["f16x3"] + macs["f16x4"] + macs["f32"], "valu": macs["valu"]}
+    elif prec == "split3":  # the mat-vec products carry six fp16 MFMA terms instead of three
+        macs = {"f16x6": macs["f16x3"], "f16x4": macs["f16x4"], "f32": macs["f32"], "valu": macs["valu"]}
     elif wgrad_f32:  # the round-2 kernels: outer products on the fp32 MFMA
         macs = {"f16x3": macs["f16x3"], "f16x4": 0, "f32": macs["f16x4"] + macs["f32"], "valu": macs["valu"]}
     flop_per_sample = 2 * sum(macs.values())
@@ -247,7 +266,7 @@ SQ_PASS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_W
            "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY"]
 
 
-def pmc_pass(counters, config, timeout_s=240):
+def pmc_pass(counters, config, precision="split3", timeout_s=240):
     """One `rocprofv3 --pmc <counters> --kernel-trace` pass over `bench.py --pmc-child` (2 steps after 1 warm-up):
     returns {counter: {kernel: average value per launch}}, or (None, reason)."""
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
@@ -256,7 +275,7 @@ def pmc_pass(counters, config, timeout_s=240):
     d = tempfile.mkdtemp(prefix="tt_pmc_", dir="/tmp")
     cmd = [exe, "--pmc"] + list(counters) + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                                             os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(config),
-                                            "--steps", "2", "--warmup", "1"]
+                                            "--precision", precision, "--steps", "2", "--warmup", "1"]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
@@ -282,14 +301,14 @@ def pmc_pass(counters, config, timeout_s=240):
     return {c: {k: acc[c][k] / cnt[c][k] for k in acc[c]} for c in acc}, None
 
 
-def pmc_traffic(config):
+def pmc_traffic(config, precision="split3"):
     """FETCH_SIZE and WRITE_SIZE (TCC) per kernel launch, each in its OWN pass (they do not fit one pass:
     MI355X_MICROARCH.md, rocprofv3 PMC slots).  Bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KiB,
     and on gfx950 FETCH_SIZE reports half of a wide coalesced read (same guide; calibrated in this workload on
     k_planes_pack: 50.3 MB read + 50.3 MB written)."""
     per = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        res, err = pmc_pass([ctr], config)
+        res, err = pmc_pass([ctr], config, precision)
         if res is None:
             return None, err
         per[ctr] = res.get(ctr, {})
@@ -301,7 +320,7 @@ def pmc_traffic(config):
     return out, None
 
 
-def pmc_pipes(config):
+def pmc_pipes(config, precision="split3"):
     """What the SIMDs did, per kernel launch, from ONE pass of SQ counters (7 of the 8 SQ slots), as ratios that need no
     clock: kernel cycles = SQ_BUSY_CYCLES / 32 shader engines; 1024 SIMDs.
       mfma_util       SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024)   -- north_star's MFMA utilisation
@@ -309,7 +328,7 @@ def pmc_pipes(config):
       issue_util      SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES
       wait_any        SQ_WAIT_ANY / SQ_WAVE_CYCLES                        -- wave parked on s_waitcnt / barrier
       waves_per_simd  4 SQ_WAVE_CYCLES / (kernel cycles x 1024)           -- average resident waves per SIMD"""
-    res, err = pmc_pass(SQ_PASS, config)
+    res, err = pmc_pass(SQ_PASS, config, precision)
     if res is None:
         return None, err
     out = {}
@@ -324,6 +343,32 @@ def pmc_pipes(config):
                   "issue_util": round(g("SQ_ACTIVE_INST_ANY") / wc, 4), "wait_any": round(g("SQ_WAIT_ANY") / wc, 4),
                   "waves_per_simd": round(4.0 * wc / (cyc * 1024.0), 3), "kernel_cycles": int(cyc),
                   "mfma_busy_cycles": int(g("SQ_VALU_MFMA_BUSY_CYCLES")), "waves": int(g("SQ_WAVES"))}
+    return out, None
+
+
+LDS_PASS = ["SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"]
+
+
+def pmc_lds(config, precision="split3"):
+    """LDS activity per kernel launch (one more SQ pass): SQ_LDS_IDX_ACTIVE = LDS-array cycles, SQ_LDS_BANK_CONFLICT = the
+    extra cycles of bank conflicts among them (MI355X_MICROARCH.md, LDS).  lds_util = LDS-array cycles / (kernel cycles x
+    256 CUs) with kernel cycles = SQ_BUSY_CYCLES / 32 as in pmc_pipes: the share of the CUs' LDS cycles in use -- the
+    binding resource of the forward-shaped kernels."""
+    res, err = pmc_pass(LDS_PASS, config, precision)
+    if res is None:
+        return None, err
+    out = {}
+    for k in res.get("SQ_BUSY_CYCLES", {}):
+        g = lambda c: res.get(c, {}).get(k, 0.0)
+        cyc = g("SQ_BUSY_CYCLES") / 32.0
+        if cyc <= 0:
+            continue
+        act = g("SQ_LDS_IDX_ACTIVE")
+        out[k] = {"lds_util": round(act / (cyc * 256.0), 4), "lds_idx_active_cycles": int(act),
+                  "lds_bank_conflict_cycles": int(g("SQ_LDS_BANK_CONFLICT")),
+                  "bank_conflict_frac": round(g("SQ_LDS_BANK_CONFLICT") / max(act, 1.0), 4),
+                  "lds_instructions": int(g("SQ_INSTS_LDS")),
+                  "lds_inst_active_frac_of_wave_cycles": round(g("SQ_ACTIVE_INST_LDS") / max(g("SQ_WAVE_CYCLES"), 1.0), 4)}
     return out, None
 
 
@@ -397,7 +442,7 @@ def dense_scene(device, inp, rc, steps=20, warmup=3):
     torch.cuda.synchronize()
     n_samples = ts.numel()
     work = work_fractions(stats, n_samples)
-    kern = {k: kernel_roofline(k, v[0], n_samples, rc.exact_f32, rc.wgrad_f32, work=work[k])
+    kern = {k: kernel_roofline(k, v[0], n_samples, rc.prec, work=work[k])
             for k, v in timer.summary(median=True).items() if k in ALG}
     for t in params:
         t.grad = None
@@ -592,12 +637,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=1, choices=(1, 3),
                     help="1 = BASELINE configs[1] per GPU (headline); 3 = configs[3]: 8 prompts x 256x256 rays per GPU")
-    ap.add_argument("--exact-f32", action="store_true",
-                    help="A/B: every matrix product on the fp32-input MFMA (TT_R_EXACT_F32) instead of split-fp16")
-    ap.add_argument("--wgrad-f32", action="store_true",
-                    help="A/B: weight-gradient outer products on the fp32 MFMA (TT_R_WGRAD_F32) instead of split-fp16")
-    ap.add_argument("--bwd-pair", action="store_true",
-                    help="A/B: the wave-pair texture backward kernel (TT_R_BWD_PAIR) instead of one wave per tile")
+    ap.add_argument("--precision", default="split3", choices=("split3", "f32", "split2"),
+                    help="MLP products: split3 = fp32-grade 3-piece split on the fp16 pipe (default, the reference's "
+                         "precision), f32 = fp32-input MFMA, split2 = the 2-piece fast mode of rounds 2-4")
+    ap.add_argument("--exact-f32", action="store_true", help="= --precision f32")
     ap.add_argument("--torch-loss", action="store_true",
                     help="A/B: the eikonal term of the G6 loss with plain torch ops instead of ops.eikonal_loss")
     ap.add_argument("--graph", action="store_true",
@@ -651,8 +694,10 @@ def main():
     R, Hh, Ww, S = 256, 256, 256, 128
     inp = make_inputs(rank, world, device, args.config, R, Hh, Ww, S)
     P = inp["cache"].shape[0]
-    rc = ops.RenderConfig(exact_f32=args.exact_f32, wgrad_f32=args.wgrad_f32, bwd_pair=args.bwd_pair, tile_sb=args.tile_sb,
-                          tile_chunk=args.tile_chunk, grad_copies=args.grad_copies)
+    if args.exact_f32:
+        args.precision = "f32"
+    rc = ops.RenderConfig(precision=args.precision, tile_sb=args.tile_sb, tile_chunk=args.tile_chunk,
+                          grad_copies=args.grad_copies)
     bucket = FlatGradBucket(inp["sw"] + inp["fw"])  # MLP grads = views of one buffer: one collective, no cat / copies
     fused = not args.torch_loss
 
@@ -759,11 +804,11 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     n_rays = P * Hh * Ww
     value = n_rays * world * args.steps / dt
-    # a window of at least 2 s of the same step (outside the K timed steps `value` comes from): long enough for a
-    # coarse GPU-activity sampler to see the run, and a check that the K-step number is sustained
+    # a window of >= 12 s of the same step (outside the K timed steps `value` comes from): several periods of a coarse
+    # GPU-activity sampler (the driver's smi poll), and a check that the K-step number is sustained
     sustained = None
-    if not args.pmc_child and not args.no_extras and dt < 2.0 and graph is None:
-        n_more = int(min(5000, max(1, (2.2 - dt) / max(dt / args.steps, 1e-4))))
+    if not args.pmc_child and not args.no_extras and graph is None:
+        n_more = int(min(20000, max(1, 12.5 / max(dt / args.steps, 1e-4))))
         barrier()
         t1 = time.perf_counter()
         for _ in range(n_more):
@@ -788,16 +833,19 @@ def main():
             ops.set_kernel_timer(None)
         ksum = timer.summary(median=True)  # label -> (median ms, launches)
         work = work_fractions(stats, n_samples)
-        kernels = {k: dict(kernel_roofline(k, ms, n_samples, args.exact_f32, args.wgrad_f32, work=work.get(k)), launches=n)
+        kernels = {k: dict(kernel_roofline(k, ms, n_samples, args.precision, work=work.get(k)), launches=n)
                    for k, (ms, n) in ksum.items() if k in ALG}
-        traffic, traffic_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_traffic(args.config)
-        pipes, pipes_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_pipes(args.config)
+        traffic, traffic_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_traffic(args.config, args.precision)
+        pipes, pipes_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_pipes(args.config, args.precision)
+        lds, lds_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_lds(args.config, args.precision)
         for k, v in kernels.items():
             dk = ALG[k]["device_kernel"]
             if traffic and dk in traffic:
                 v["pmc"] = dict(traffic[dk], kernel=dk)
             if pipes and dk in pipes:
                 v["sq"] = dict(pipes[dk], kernel=dk)
+            if lds and dk in lds:
+                v["lds"] = dict(lds[dk], kernel=dk)
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         kd = kernels[dom]
         if kd["bound_8d"] == "hbm":
@@ -849,13 +897,7 @@ def main():
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_median_hipevent": round(statistics.median(step_ms), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_EXACT if args.exact_f32 else DTYPE,
-            "dtype_note": ("TT_R_EXACT_F32: every matrix product on v_mfma_f32_32x32x2_f32" if args.exact_f32 else
-                           "fp32 storage, accumulation and element-wise math; every mat-vec product as a 2-term "
-                           "split-fp16 product (v = hi + lo with round-to-nearest-even splits, operands normalised to the top "
-                           "of the fp16 range, ~24-bit significands, 3 x v_mfma_f32_32x32x16_f16 into one fp32 accumulator) except the f32 MACs "
-                           "listed in profiles/README.md (weight-gradient outer products, texture scatter GEMM); the "
-                           "strict-fp32 number of the same build is `exact_f32` below"),
+            "dtype": DTYPES[args.precision], "precision": args.precision, "dtype_note": DTYPE_NOTES[args.precision],
             "data": "synthetic",
             "config": {"workload": cfg_name + ", 128 uniform samples on [0.1,4.0], fwd + bwd of the G6 loss (d/d planes + "
                                               "d/d 6 MLP matrices, second-order normal path included)",
@@ -868,26 +910,40 @@ def main():
         if world > 1:
             line["multi_gpu"] = {"per_rank_ms_per_step": per_rank_ms, "allreduce_us": allreduce_us,
                                  "allreduce_bytes": bucket.flat_grad.numel() * 4, "rccl": ranks_seen}
-        if world == 1 and not args.no_extras and not args.exact_f32:
-            # strict-fp32 sub-result of the same build (driver-visible): the SAME number of steps with TT_R_EXACT_F32
-            rcx = ops.RenderConfig(exact_f32=True)
-            stepx = make_step(rcx)
-            for _ in range(3):
-                stepx()
-            tx = ops.KernelTimer()
-            ops.set_kernel_timer(tx)
-            nx = max(args.steps, 20)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(nx):
-                stepx()
-            torch.cuda.synchronize()
-            dtx = (time.perf_counter() - t0) / nx
-            ops.set_kernel_timer(None)
-            line["exact_f32"] = {"dtype": DTYPE_EXACT, "steps": nx, "ms_per_step": round(dtx * 1e3, 4),
-                                 "value": round(n_rays / dtx, 1), "unit": "rays/s",
-                                 "kernels": {k: kernel_roofline(k, ms, n_samples, True, work=work.get(k))
-                                             for k, (ms, n) in tx.summary(median=True).items() if k in ALG}}
+        if world == 1 and not args.no_extras:
+            # the other two precision modes of the same build, over the SAME number of steps, with their own rooflines and
+            # SQ counters (driver-visible): "f32" = the fp32-input MFMA (physical MFMA utilisation of an fp32 GEMM
+            # pipe), "split2" = the fast mode
+            line["modes"] = {}
+            for mode in ("split3", "f32", "split2"):
+                if mode == args.precision:
+                    continue
+                rcx = ops.RenderConfig(precision=mode)
+                stepx = make_step(rcx)
+                for _ in range(3):
+                    stepx()
+                tx = ops.KernelTimer()
+                ops.set_kernel_timer(tx)
+                nx = max(args.steps, 20)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(nx):
+                    stepx()
+                torch.cuda.synchronize()
+                dtx = (time.perf_counter() - t0) / nx
+                ops.set_kernel_timer(None)
+                km = {k: kernel_roofline(k, ms, n_samples, mode, work=work.get(k))
+                      for k, (ms, n) in tx.summary(median=True).items() if k in ALG}
+                if not args.no_pmc:
+                    pm, pm_err = pmc_pipes(args.config, mode)
+                    for k, v in km.items():
+                        dk = ALG[k]["device_kernel"]
+                        if pm and dk in pm:
+                            v["sq"] = dict(pm[dk], kernel=dk)
+                        elif pm is None:
+                            v["sq"] = {"error": pm_err}
+                line["modes"][mode] = {"dtype": DTYPES[mode], "steps": nx, "ms_per_step": round(dtx * 1e3, 4),
+                                       "value": round(n_rays / dtx, 1), "unit": "rays/s", "kernels": km}
             try:
                 line["secondary"] = secondary_workloads(device, inp, rc=rc)
             except Exception as e:  # the headline must not depend on the extras

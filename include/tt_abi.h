@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 15
+#define TT_ABI_VERSION 16
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -145,22 +145,36 @@ typedef struct {
 } tt_render_cfg;
 
 #define TT_R_PER_SAMPLE 1 /* also write per-sample sdf / sdf_grad / features (training extras, renderer :532-545) */
-#define TT_R_EXACT_F32 2  /* every matrix product on the fp32-input MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fmaf
-                             chain) instead of the default 2-term split-fp16 products (22-bit significands, fp32
-                             accumulation, ~5x less matrix-pipe time): the A/B reference of that scheme, and an opt-out */
+/* ---- precision of the matrix products (the per-point MLPs; everything else is plain fp32 in every mode) ----
+ * The reference multiplies in fp32 (threestudio/models/networks.py:91-97: nn.Linear with autocast disabled; trainer
+ * precision 32, configs/TriplaneTurbo_v1.yaml:254).  Three modes; at most one of the three bits may be set, none = the
+ * default = TT_R_SPLIT3:
+ *   TT_R_SPLIT3     fp32-GRADE products on the fp16 matrix pipe: every operand is split EXACTLY in three fp16 pieces
+ *                   (hi + mid + lo = v), the six product terms above 2^-33 are accumulated in fp32 (6 x
+ *                   v_mfma_f32_32x32x16_f16 per k-step).  Product error <= 2^-24 of sum |a b| (tools/mfma16_probe.hip):
+ *                   the reference's precision at ~1/3 of the fp32 MFMA's matrix-pipe time.
+ *   TT_R_EXACT_F32  every product on the fp32-input MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain).  The A/B
+ *                   reference of the split modes.
+ *   TT_R_SPLIT2     the FAST mode (the default of rounds 2-4): two fp16 pieces per operand, three product terms, ~2^-21.5
+ *                   per product -- a tolerance-bounded approximation (gradients within 1e-4 of the fp32 math on
+ *                   well-conditioned scenes, not on every scene: DESIGN.md section 6). */
+#define TT_R_EXACT_F32 2
+#define TT_R_SPLIT2 32
+#define TT_R_SPLIT3 64
 
-#define TT_R_WGRAD_F32 4  /* backward: weight-gradient outer products on the fp32-input MFMA (implied by TT_R_EXACT_F32)
-                             instead of the default split-fp16 products with per-launch operand scales; A/B switch */
-
+#define TT_R_WGRAD_F32 4  /* TUNING BUILD ONLY (-DTT_TUNING; the product library returns TT_ERR_UNSUPPORTED): backward
+                             weight-gradient outer products on the fp32-input MFMA instead of split-fp16 products with
+                             per-launch operand scales; the round-2 A/B switch, TT_R_SPLIT2 only */
 #define TT_R_BWD_SOLO 8   /* backward: force the one-wave-per-tile decode kernels (the default) */
-#define TT_R_BWD_PAIR 16  /* backward: the wave-pair texture kernel (two waves share a 32-sample tile and split every hidden
-                             layer and the weight-gradient accumulators: 256 registers, two waves per SIMD); A/B switch,
-                             default precision only, bit-for-bit the same arithmetic up to summation order */
+#define TT_R_BWD_PAIR 16  /* TUNING BUILD ONLY (the product library returns TT_ERR_UNSUPPORTED): the experimental wave-pair
+                             texture kernel of round 4 (csrc/tt_backward_tex2.hip), TT_R_SPLIT2 only */
 
 /* tt_query_points / tt_query_field / tt_decode_rays / tt_points_bwd_* flags */
 #define TT_Q_NORMAL 1    /* output sdf_grad (analytic normal path) */
 #define TT_Q_TEX 2       /* output features (texture planes + feature net) */
 #define TT_Q_EXACT_F32 4 /* as TT_R_EXACT_F32 */
+#define TT_Q_SPLIT2 8    /* as TT_R_SPLIT2 */
+#define TT_Q_SPLIT3 16   /* as TT_R_SPLIT3 (the default) */
 
 const char* tt_strerror(int status);
 int tt_abi_version(void);

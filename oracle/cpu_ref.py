@@ -49,6 +49,46 @@ import torch.nn.functional as F
 
 Tensor = torch.Tensor
 
+# --------------------------------------------------------------------------
+# A SECOND fp32 evaluation order (round 5): the same math, different rounding
+# --------------------------------------------------------------------------
+# fp32 arithmetic does not define ONE answer for this renderer: NeuS alpha is a ratio of nearly equal sigmoids scaled by
+# inv_std = 100, so in ill-conditioned scenes two correct fp32 evaluations that merely add in a different order differ by
+# 1e-4 ... 1e-2 in the gradients.  To MEASURE that sensitivity per case (instead of inferring it from the distance to
+# fp64), every sum in the decode can be evaluated in a second, documented order:
+#   * nn.Linear (vanilla_mlp): the K input channels in REVERSED order, accumulated in blocks of 8 (block partial sums
+#     first, blocks added last-to-first) -- the reference / default order is torch's GEMM over k = 0 .. K-1;
+#   * bilinear blend (grid_sample_gather): corners se, sw, ne, nw instead of nw, ne, sw, se;
+#   * v1 plane sum (sample_from_planes): planes 2, 1, 0 instead of 0, 1, 2;
+#   * accumulate_along_rays (render): samples far-to-near instead of near-to-far.
+# Same operations, same operands, same dtype: |fp32 - fp32'| is the order sensitivity of the fp32 oracle itself, and
+# tests/parity.py asks of the HIP path  |hip - fp32| <= max(1e-4, 1.5 |fp32 - fp32'|).
+_ALT_ORDER = False
+
+
+@contextlib.contextmanager
+def alt_order(on: bool = True):
+    """Evaluate every sum of the decode / march in the second operation order described above."""
+    global _ALT_ORDER
+    prev, _ALT_ORDER = _ALT_ORDER, bool(on)
+    try:
+        yield
+    finally:
+        _ALT_ORDER = prev
+
+
+def _linear(x: Tensor, w: Tensor) -> Tensor:
+    """F.linear(x, w) -- or, under alt_order(), the same product with the channels reversed and accumulated in blocks of 8."""
+    if not _ALT_ORDER:
+        return F.linear(x, w)
+    K = w.shape[1]
+    out = None
+    for k1 in range(K, 0, -8):  # blocks last-to-first
+        k0 = max(k1 - 8, 0)
+        part = F.linear(x[..., k0:k1].flip(-1), w[:, k0:k1].flip(-1))
+        out = part if out is None else out + part
+    return out
+
 
 # --------------------------------------------------------------------------
 # plane re-orientation, projection, bilinear sampling
@@ -132,7 +172,8 @@ def grid_sample_gather(inp: Tensor, grid: Tensor, padding_mode: str = "zeros", a
     N, C, H, W = inp.shape
     flat = inp.permute(0, 2, 3, 1).reshape(N, H * W, C)
     out = None
-    for cy, cx, w, inb in bilinear_corners(grid, H, W, padding_mode, align_corners):
+    corners = bilinear_corners(grid, H, W, padding_mode, align_corners)
+    for cy, cx, w, inb in (corners[::-1] if _ALT_ORDER else corners):
         idx = (cy.clamp(0, H - 1) * W + cx.clamp(0, W - 1)).long()  # (N, M)
         val = torch.gather(flat, 1, idx[..., None].expand(-1, -1, C))
         val = val * inb[..., None].to(inp.dtype)
@@ -154,6 +195,8 @@ def sample_from_planes(plane_features: Tensor, coordinates: Tensor, interpolate_
     feats = grid_sample_gather(plane_features.reshape(N * n_planes, C, H, W), proj)
     feats = feats.reshape(N, n_planes, M, C)
     if interpolate_feat in (None, "v1"):
+        if _ALT_ORDER:
+            return (feats[:, 2] + feats[:, 1]) + feats[:, 0]
         return feats.sum(dim=1)
     elif interpolate_feat == "v2":
         return feats.permute(0, 2, 1, 3).reshape(N, M, n_planes * C)
@@ -166,7 +209,7 @@ def sample_from_planes(plane_features: Tensor, coordinates: Tensor, interpolate_
 def vanilla_mlp(x: Tensor, weights: Sequence[Tensor]) -> Tensor:
     """threestudio/models/networks.py:67-104 -- Linear(bias=False)+ReLU, no output activation."""
     for i, w in enumerate(weights):
-        x = F.linear(x, w)
+        x = _linear(x, w)
         if i + 1 < len(weights):
             x = torch.relu(x)
     return x
@@ -312,7 +355,13 @@ def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Seq
     def accumulate(values: Optional[Tensor]) -> Tensor:
         # nerfacc.accumulate_along_rays (call sites :414-431, :467-472)
         src = weights if values is None else weights * values
-        return src.reshape(n_rays, S, -1).sum(dim=1)
+        src = src.reshape(n_rays, S, -1)
+        if _ALT_ORDER:  # far-to-near, one sample at a time
+            acc = src[:, S - 1]
+            for k in range(S - 2, -1, -1):
+                acc = acc + src[:, k]
+            return acc
+        return src.sum(dim=1)
 
     opacity = accumulate(None)
     depth = accumulate(t_positions)

@@ -8,7 +8,7 @@ import torch
 
 from oracle import cpu_ref as O
 
-from parity import check_grads  # noqa: E402
+from parity import PRECISIONS, check_grads  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -43,14 +43,16 @@ def _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rc_kwargs
     return out, loss.item(), [g.cpu() for g in grads]
 
 
-def _oracle_grads(dtype, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rc_kwargs):
+def _oracle_grads(dtype, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rc_kwargs, alt_order=False):
+    """alt_order: the oracle's second operation order (oracle/cpu_ref.py: alt_order) -- same math, other rounding."""
     d = dtype
     c = cache.to(d).requires_grad_(True)
     sws = [w.to(d).requires_grad_(True) for w in sw]
     fws = [w.to(d).requires_grad_(True) for w in fw]
-    out = O.render(c, sws, fws, ro.to(d), rd.to(d), ts.to(d), te.to(d), bg.to(d), cd.to(d), c2w.to(d), **rc_kwargs)
-    loss = O.synthetic_loss(out, {k: v.to(d) for k, v in proj.items()})
-    grads = torch.autograd.grad(loss, [c] + sws + fws)
+    with O.alt_order(alt_order):
+        out = O.render(c, sws, fws, ro.to(d), rd.to(d), ts.to(d), te.to(d), bg.to(d), cd.to(d), c2w.to(d), **rc_kwargs)
+        loss = O.synthetic_loss(out, {k: v.to(d) for k, v in proj.items()})
+        grads = torch.autograd.grad(loss, [c] + sws + fws)
     return out, loss.item(), list(grads)
 
 
@@ -68,14 +70,14 @@ def _check(g_hip, g32, g64, tol=1e-4, elem=True, **kw):
     return check_grads(case, g_hip, g32, g64, tol64=tol, elem=elem, **kw)
 
 
-@pytest.mark.parametrize("exact_f32", [False, True])
-def test_backward_small_golden(mods, golden_dir, exact_f32):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_backward_small_golden(mods, golden_dir, precision):
     k = dict(np.load(os.path.join(golden_dir, "render_small.npz")))
     kref = dict(np.load(os.path.join(golden_dir, "reference_renderer.npz")))  # the REFERENCE renderer's own results
     sw = [T(k[f"sdf_w{i}"]) for i in range(3)]
     fw = [T(k[f"feat_w{i}"]) for i in range(3)]
     proj = {n: T(k[f"proj_{n}"]) for n, _ in KEYS}
-    rck = dict(inv_std=100.0, rgb_grad_shrink=0.5, exact_f32=exact_f32)
+    rck = dict(inv_std=100.0, rgb_grad_shrink=0.5, precision=precision)
     out, loss, g = _hip_grads(mods, T(k["cache"]), sw, fw, T(k["rays_o"]), T(k["rays_d"]), T(k["t_starts"]),
                               T(k["t_ends"]), T(k["bg"]), T(k["cam_d"]), T(k["c2w"]), proj, rck)
     g64 = [T(k["f64_g_cache"])] + [T(k[f"f64_g_sdf_w{i}"]) for i in range(3)] + [T(k[f"f64_g_feat_w{i}"]) for i in
@@ -94,7 +96,7 @@ def test_backward_small_golden(mods, golden_dir, exact_f32):
         T(kref[f"f32_g_feat_w{i}"]) for i in range(3)]
     gr64 = [T(kref["f64_g_cache"])] + [T(kref[f"f64_g_sdf_w{i}"]) for i in range(3)] + [
         T(kref[f"f64_g_feat_w{i}"]) for i in range(3)]
-    print(check_grads("golden case vs the reference renderer's own gradients" + (" [exact_f32]" if exact_f32 else ""),
+    print(check_grads("golden case vs the reference renderer's own gradients" + (f" [{precision}]"),
                       g, gr32, gr64))
     for key in ("comp_rgb", "opacity", "depth", "z_variance", "disparity", "comp_normal", "comp_normal_cam_vis",
                 "comp_normal_cam_vis_white", "weights", "sdf", "sdf_orig", "features", "sdf_grad", "normal", "points",
@@ -112,8 +114,8 @@ def test_backward_small_golden(mods, golden_dir, exact_f32):
     (1, 128, 1, 24, 24, 32, 3),  # BASELINE config[0] planes, reduced ray count (CPU double backward is slow)
     (1, 40, 3, 9, 11, 19, 4),    # plane size not a power of two, 3 views of one prompt, odd sizes everywhere
 ])
-@pytest.mark.parametrize("exact_f32", [False, True])
-def test_backward_matches_oracle(mods, P, R, n_view, Hh, Ww, S, seed, exact_f32):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_backward_matches_oracle(mods, P, R, n_view, Hh, Ww, S, seed, precision):
     g = torch.Generator().manual_seed(seed)
     cache = torch.randn(P, 6, 32, R, R, generator=g) * 0.5
     sw = O.init_mlp_weights([32, 64, 64, 1], g)
@@ -124,7 +126,7 @@ def test_backward_matches_oracle(mods, P, R, n_view, Hh, Ww, S, seed, exact_f32)
     bg = torch.ones(3)
     proj = {n: torch.randn(P * n_view, Hh, Ww, c, generator=g) for n, c in KEYS}
     rck = dict(inv_std=100.0, rgb_grad_shrink=0.7, cos_anneal_ratio=1.0)
-    _, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, dict(rck, exact_f32=exact_f32))
+    _, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, dict(rck, precision=precision))
     _, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
     _, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
     assert abs(l_hip - l64) <= max(4 * abs(l32 - l64), 1e-5 * abs(l64))
@@ -164,8 +166,8 @@ def test_every_tiling_matches_oracle(mods, chunk, blocked, sb, monkeypatch):
     _check(g_hip, g32, g64)
 
 
-@pytest.mark.parametrize("sb,copies,exact_f32", [(1, 1, False), (4, 3, False), (32, 2, False), (8, 1, True)])
-def test_sparse_rays_take_the_direct_scatter_path(mods, sb, copies, exact_f32, monkeypatch):
+@pytest.mark.parametrize("sb,copies,precision", [(1, 1, "split3"), (4, 3, "split3"), (32, 2, "split2"), (8, 1, "f32")])
+def test_sparse_rays_take_the_direct_scatter_path(mods, sb, copies, precision, monkeypatch):
     """Rays several texels apart (9x6 rays over 128x128 planes): a tile's footprint is far wider than the 8x8 slot
     window of the matrix-core combine, so most corner references lose their slot and go through the direct
     half-wave-per-reference scatter.  Also covers privatised gradient copies (cfg.grad_copies > 1)."""
@@ -182,7 +184,7 @@ def test_sparse_rays_take_the_direct_scatter_path(mods, sb, copies, exact_f32, m
     proj = {n: torch.randn(P * n_view, Hh, Ww, c, generator=g) for n, c in KEYS}
     rck = dict(inv_std=60.0, rgb_grad_shrink=1.0, cos_anneal_ratio=0.5)
     out, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj,
-                                   dict(rck, grad_copies=copies, tile_sb=sb, exact_f32=exact_f32))
+                                   dict(rck, grad_copies=copies, tile_sb=sb, precision=precision))
     o32, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
     o64, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
     _check(g_hip, g32, g64)

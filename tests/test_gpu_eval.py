@@ -10,7 +10,7 @@ import torch
 
 from oracle import cpu_ref as O
 
-from parity import report
+from parity import PRECISIONS, report
 
 pytestmark = pytest.mark.gpu
 
@@ -30,12 +30,12 @@ def _setup(P, R, n_view, Hh, Ww, S, seed, near=0.3, far=3.2):
     return ops, args, (cache, sw, fw, ro, rd, ts, te, c2w, cd)
 
 
-@pytest.mark.parametrize("exact_f32", [False, True])
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("P,R,n_view,Hh,Ww,S,seed", [(1, 32, 1, 8, 8, 32, 1), (2, 48, 2, 13, 9, 45, 2),
                                                      (1, 64, 1, 33, 30, 70, 3)])
-def test_eval_kernel_matches_training_forward_and_oracle(P, R, n_view, Hh, Ww, S, seed, exact_f32):
+def test_eval_kernel_matches_training_forward_and_oracle(P, R, n_view, Hh, Ww, S, seed, precision):
     ops, args, (cache, sw, fw, ro, rd, ts, te, c2w, cd) = _setup(P, R, n_view, Hh, Ww, S, seed)
-    rc = ops.RenderConfig(inv_std=100.0, exact_f32=exact_f32)
+    rc = ops.RenderConfig(inv_std=100.0, precision=precision)
     want = ops.render_forward_raw(*args, rc, image_w=Ww)
     got = ops.render_eval_raw(*args, rc, image_w=Ww)  # thresholds 0: nothing approximated
     for k in ("opacity", "depth", "rgb_fg", "z_variance", "normal_acc"):

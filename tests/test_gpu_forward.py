@@ -7,6 +7,8 @@ import torch
 
 from oracle import cpu_ref as O
 
+from parity import PRECISIONS  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -67,9 +69,9 @@ def test_query_points_matches_reference_golden(ops, golden_dir):
     torch.testing.assert_close(grad.cpu().view(B, N, 3), T(ref["g4_sdf_grad"]), rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("exact_f32", [False, True])
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("R,N", [(16, 33), (48, 777), (128, 5000), (256, 4096)])  # 48: not a power of two
-def test_query_points_matches_oracle(ops, R, N, exact_f32):
+def test_query_points_matches_oracle(ops, R, N, precision):
     g = torch.Generator().manual_seed(R + N)
     P, n_view = 2, 2
     cache = torch.randn(P, 6, 32, R, R, generator=g) * 0.5
@@ -81,7 +83,7 @@ def test_query_points_matches_oracle(ops, R, N, exact_f32):
                                 [w.double() for w in fw], output_normal=True)
     packed = ops.planes_pack(cache.cuda())
     sdf, grad, feat = ops.query_points(packed, [w.cuda() for w in sw], [w.cuda() for w in fw], pts.cuda(),
-                                       views_per_prompt=n_view, exact_f32=exact_f32)
+                                       views_per_prompt=n_view, precision=precision)
     for name, got in (("sdf", sdf), ("sdf_grad", grad), ("features", feat)):
         got = got.cpu()
         w32, w64 = want[name], want64[name]
@@ -93,12 +95,12 @@ def test_query_points_matches_oracle(ops, R, N, exact_f32):
         assert err_hip <= max(4 * err_cpu, 1e-5 * scale), (name, err_hip, err_cpu, scale)
     # sdf-only path (forward_sdf, few_step...:353-373)
     sdf2, g2, f2 = ops.query_points(packed, [w.cuda() for w in sw], None, pts.cuda(), views_per_prompt=n_view,
-                                    need_normal=False, need_features=False, exact_f32=exact_f32)
+                                    need_normal=False, need_features=False, precision=precision)
     assert g2 is None and f2 is None
     torch.testing.assert_close(sdf2, sdf, rtol=0, atol=0)
 
 
-def _compare_render(ops, scene, n_view, rgb_shrink=1.0, S_tol=1.0, exact_f32=False):
+def _compare_render(ops, scene, n_view, rgb_shrink=1.0, S_tol=1.0, precision=None):
     cache, sw, fw, ro, rd, c2w, cd, ts, te = scene
     P = cache.shape[0]
     B, Hh, Ww, _ = ro.shape
@@ -110,7 +112,7 @@ def _compare_render(ops, scene, n_view, rgb_shrink=1.0, S_tol=1.0, exact_f32=Fal
     packed = ops.planes_pack(cache.cuda())
     raw = ops.render_forward_raw(packed, [w.cuda() for w in sw], [w.cuda() for w in fw], ro.reshape(-1, 3).cuda(),
                                  rd.reshape(-1, 3).cuda(), ts.cuda(), te.cuda(), Hh * Ww,
-                                 ops.RenderConfig(exact_f32=exact_f32))
+                                 ops.RenderConfig(precision=precision))
     raw = {k: v.cpu() for k, v in raw.items()}
     n_rays = B * Hh * Ww
     pairs = {
@@ -166,16 +168,16 @@ def test_render_fwd_small_golden(ops, golden_dir):
         assert err_hip <= max(4 * err_cpu, 2e-5 * scale), (name, err_hip, err_cpu, scale)
 
 
-@pytest.mark.parametrize("exact_f32", [False, True])
-def test_render_fwd_c1_like(ops, exact_f32):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_render_fwd_c1_like(ops, precision):
     """BASELINE config[0] shape (planes 128^2, 64x64 rays, 32 samples), P=1 view=1."""
     scene = _scene(seed=5, P=1, R=128, n_view=1, Hh=64, Ww=64, S=32)
-    rep = _compare_render(ops, scene, 1, exact_f32=exact_f32)
+    rep = _compare_render(ops, scene, 1, precision=precision)
     print(rep)
 
 
-@pytest.mark.parametrize("exact_f32", [False, True])
-def test_render_fwd_multi_prompt_ragged_tile(ops, exact_f32):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_render_fwd_multi_prompt_ragged_tile(ops, precision):
     """2 prompts x 2 views, S=45 (last tile partially filled), small planes."""
     scene = _scene(seed=6, P=2, R=32, n_view=2, Hh=5, Ww=7, S=45, near=0.4, far=2.9)
-    _compare_render(ops, scene, 2, exact_f32=exact_f32)
+    _compare_render(ops, scene, 2, precision=precision)

@@ -5,6 +5,8 @@ import torch
 
 from oracle import cpu_ref as O
 
+from parity import PRECISIONS  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -121,8 +123,8 @@ def band_oracle(full):
     return res
 
 
-@pytest.mark.parametrize("exact_f32", [False, True])
-def test_gradient_parity_on_configs1_own_inputs(full, band_oracle, exact_f32):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_gradient_parity_on_configs1_own_inputs(full, band_oracle, precision):
     """Oracle gradients ON configs[1]'s OWN inputs (planes (1,6,32,256,256), its camera, its 128 samples on
     [0.1, 4.0], its G6 loss): a 4-row band of the 256x256 ray image through the middle of the object (1024 rays x 128
     samples = 131 072 samples) goes through the HIP forward + backward and through the fp32 / fp64 CPU oracle.
@@ -137,7 +139,7 @@ def test_gradient_parity_on_configs1_own_inputs(full, band_oracle, exact_f32):
     n = rows * Ww
     ts, te = inp["ts"][:n].contiguous(), inp["te"][:n].contiguous()
     proj = {k: v[:, r0:r0 + rows].contiguous() for k, v in inp["proj"].items()}
-    rc = ops.RenderConfig(exact_f32=exact_f32)
+    rc = ops.RenderConfig(precision=precision)
     c = inp["cache"].detach().clone().requires_grad_(True)
     sws = [w.detach().clone().requires_grad_(True) for w in inp["sw"]]
     fws = [w.detach().clone().requires_grad_(True) for w in inp["fw"]]
@@ -146,4 +148,4 @@ def test_gradient_parity_on_configs1_own_inputs(full, band_oracle, exact_f32):
     g_hip = [g.cpu() for g in torch.autograd.grad(loss, [c] + sws + fws)]
     (l32, g32), (l64, g64) = band_oracle
     assert abs(float(loss) - l64) <= max(4 * abs(l32 - l64), 1e-5 * abs(l64)), (float(loss), l32, l64)
-    check_grads(f"configs[1] own inputs, rows {r0}..{r0 + rows - 1} (exact_f32={exact_f32})", g_hip, g32, g64)
+    check_grads(f"configs[1] own inputs, rows {r0}..{r0 + rows - 1} (precision={precision})", g_hip, g32, g64)

@@ -9,6 +9,8 @@ import torch
 import triplaneturbo_amd as tt
 from oracle import cpu_ref as O
 
+from parity import PRECISIONS  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -22,13 +24,13 @@ def _check(g_hip, g32, g64, names):
         assert e_hip <= max(1e-4, 3 * e_cpu), (n, e_hip, e_cpu)
 
 
-@pytest.mark.parametrize("exact_f32", [False, True])
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("output_normal", [True, False])
-def test_geometry_forward_is_differentiable(output_normal, exact_f32):
+def test_geometry_forward_is_differentiable(output_normal, precision):
     dev = torch.device("cuda", 0)
     torch.manual_seed(11)
     g = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
-    g.exact_f32 = exact_f32
+    g.precision = precision
     gen = torch.Generator().manual_seed(12)
     P, vpp, N, R = 2, 2, 333, 32
     cache = torch.randn(P, 6, 32, R, R, generator=gen) * 0.5
@@ -63,12 +65,12 @@ def test_geometry_forward_is_differentiable(output_normal, exact_f32):
         assert not g(pts.to(dev), c, output_normal=output_normal)["sdf"].requires_grad
 
 
-@pytest.mark.parametrize("exact_f32", [False, True])
-def test_forward_field_is_differentiable(exact_f32):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_field_is_differentiable(precision):
     dev = torch.device("cuda", 0)
     torch.manual_seed(13)
     g = tt.find("few-step-triplane-dual-stable-diffusion")({"isosurface_deformable_grid": True}).to(dev)
-    g.exact_f32 = exact_f32
+    g.precision = precision
     gen = torch.Generator().manual_seed(14)
     R = 32
     cache = torch.randn(1, 6, 32, R, R, generator=gen) * 0.5
@@ -99,9 +101,9 @@ def test_forward_field_is_differentiable(exact_f32):
     assert g_hip[0][:, 3:].abs().max().item() == 0.0  # texture planes are not touched by the field query
 
 
-@pytest.mark.parametrize("exact_f32", [False, True])
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("output_normal", [True, False])
-def test_gradient_wrt_the_query_points(output_normal, exact_f32):
+def test_gradient_wrt_the_query_points(output_normal, precision):
     """the raster renderer decodes positions interpolated from differentiable mesh vertices, so
     d loss / d points must flow (first order through sdf / features, second order through sdf_grad / normal: K1's
     grad_grid output, gridsample_cuda.cu:196-208).  Against autograd of the oracle with points.requires_grad_()."""
@@ -109,7 +111,7 @@ def test_gradient_wrt_the_query_points(output_normal, exact_f32):
     dev = torch.device("cuda", 0)
     torch.manual_seed(21)
     g = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
-    g.exact_f32 = exact_f32
+    g.precision = precision
     gen = torch.Generator().manual_seed(22)
     P, vpp, N, R = 2, 2, 257, 48
     cache = torch.randn(P, 6, 32, R, R, generator=gen) * 0.5
@@ -135,7 +137,7 @@ def test_gradient_wrt_the_query_points(output_normal, exact_f32):
     loss = sum((out[k] * proj[k].to(dev)).sum() for k in keys)
     gx, gc = torch.autograd.grad(loss, [x, c])
     e_hip, e_cpu, e_32 = _rel(gx.cpu(), gx64), _rel(gx32, gx64), _rel(gx.cpu(), gx32)
-    report(f"d/d points of geometry.forward (output_normal={output_normal}, exact_f32={exact_f32})",
+    report(f"d/d points of geometry.forward (output_normal={output_normal}, precision={precision})",
            {"hip_vs_fp64": e_hip, "fp32_vs_fp64": e_cpu, "hip_vs_fp32": e_32})
     assert e_hip <= max(1e-4, 3 * e_cpu), (e_hip, e_cpu)
     assert e_32 <= 1e-4, e_32

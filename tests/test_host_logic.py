@@ -177,7 +177,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == _lib._expected_abi() == 15
+    assert lib.tt_abi_version() == _lib._expected_abi() == 16
     assert b"bad argument" in lib.tt_strerror(-1)
     # the binary carries the hash of the sources + flags it was built from, and that is what "up to date" means
     lib.tt_source_hash.restype = ctypes.c_char_p

@@ -34,14 +34,19 @@ if jittered:
     ts, te = edges[:, :-1].contiguous(), edges[:, 1:].contiguous()
 bg = torch.rand(3, generator=g)
 proj = {n: torch.randn(P * n_view, Hh, Ww, c, generator=g) for n, c in KEYS}
+if not os.environ.get("TT_FUZZ_NO_KINK_MASK"):  # as the fuzz test does
+    from parity import kink_free_rays  # noqa: E402
+    keep = kink_free_rays(cache, sw, fw, ro, rd, ts, te, n_view)
+    print("kink-free rays", int(keep.sum()), "of", keep.numel())
+    proj = {n: v * keep.view(P * n_view, Hh, Ww, 1).to(v.dtype) for n, v in proj.items()}
 dev = "cuda"
 
 
-def hip(exact, keys=None):
+def hip(precision, keys=None):
     c = cache.to(dev).requires_grad_(True)
     sws = [w.to(dev).requires_grad_(True) for w in sw]
     fws = [w.to(dev).requires_grad_(True) for w in fw]
-    rc = ops.RenderConfig(**dict(rck, exact_f32=exact))
+    rc = ops.RenderConfig(**dict(rck, precision=precision, **{k: v for k, v in knobs.items() if k != "precision"}))
     out = functional.volume_render(c, sws, fws, ro.to(dev), rd.to(dev), ts.to(dev), te.to(dev), bg.to(dev), cd.to(dev),
                                    c2w.to(dev), rc, training=True)
     res = {}
@@ -74,8 +79,8 @@ def oracle(dt):
     return res, grads
 
 
-rd_, gd = hip(False)
-rx, gx = hip(True)
+rd_, gd = hip(os.environ.get("TT_DEBUG_MODE", "split3"))  # "default" columns below = this mode
+rx, gx = hip("f32")
 r64, g64 = oracle(torch.float64)
 r32, g32 = oracle(torch.float32)
 print("seed", seed, rck, "P", P, "views", n_view, "R", R, Hh, Ww, "S", S)
@@ -123,3 +128,27 @@ for idx in torch.argsort(err_d, descending=True)[:6].tolist():
     print(f"  sample {idx}: {err_d[idx]:.2e} / {err_x[idx]:.2e}   layer1 {near1[idx]:.2e}  layer2 {near2[idx]:.2e}")
 print("all samples: fraction with a pre-activation closer than 2^-20 / 2^-22 / 2^-24 of its sum|w||x|:",
       [float(((near1 < t) | (near2 < t)).double().mean()) for t in (2.0 ** -20, 2.0 ** -22, 2.0 ** -24)], "of", err_d.numel())
+
+# ---- discrete events of the march: alpha at a clip boundary, cos(theta) at the relu kink ----
+with torch.no_grad():
+    w_d, w_x, w_32, w_64 = (r["weights"].reshape(-1) for r in (rd_, rx, r32, r64))
+    dw = (w_d - w_32).abs()
+    print("samples with the largest |weights(mode) - weights(fp32 oracle)|: mode / f32-mode / fp32 oracle / fp64; sdf of each")
+    for idx in torch.argsort(dw, descending=True)[:8].tolist():
+        print(f"  sample {idx} (ray {idx // S}, s {idx % S}): w {w_d[idx]:.6e} / {w_x[idx]:.6e} / {w_32[idx]:.6e} / {w_64[idx]:.6e}   "
+              f"sdf {rd_['sdf'].reshape(-1)[idx]:.8e} / {rx['sdf'].reshape(-1)[idx]:.8e} / {r32['sdf'].reshape(-1)[idx]:.8e} / {r64['sdf'].reshape(-1)[idx]:.8e}")
+    # fp64 alpha terms per sample
+    n64 = torch.nn.functional.normalize(r64["sdf_grad"].reshape(-1, 3), dim=-1)
+    t_dirs = rd.reshape(-1, 3).double().repeat_interleave(S, 0)
+    cosv = (t_dirs * n64).sum(-1)
+    dists = (te - ts).reshape(-1).double()
+    k = rck["inv_std"]
+    car = rck["cos_anneal_ratio"]
+    ic = -(torch.relu(-cosv * 0.5 + 0.5) * (1 - car) + torch.relu(-cosv) * car)
+    sd = r64["sdf"].reshape(-1)
+    prev, nxt = torch.sigmoid((sd - ic * dists * 0.5) * k), torch.sigmoid((sd + ic * dists * 0.5) * k)
+    ratio = (prev - nxt + 1e-5) / (prev + 1e-5)
+    print("fp64: samples whose alpha ratio is within 1e-5 of a clip bound (0 / 1):", int(((ratio.abs() < 1e-5) | ((ratio - 1).abs() < 1e-5)).sum()),
+          "  |cos| < 1e-5:", int((cosv.abs() < 1e-5).sum()), " of", ratio.numel())
+    for idx in torch.argsort(dw, descending=True)[:4].tolist():
+        print(f"  sample {idx}: cos {cosv[idx]:.3e} ratio {ratio[idx]:.6e} prev_cdf {prev[idx]:.3e} next_cdf {nxt[idx]:.3e}")

@@ -218,9 +218,43 @@ TT_R_EXACT_F32 = 2
 TT_R_WGRAD_F32 = 4
 TT_R_BWD_SOLO = 8
 TT_R_BWD_PAIR = 16
+TT_R_SPLIT2 = 32
+TT_R_SPLIT3 = 64
 TT_Q_NORMAL = 1
 TT_Q_TEX = 2
 TT_Q_EXACT_F32 = 4
+TT_Q_SPLIT2 = 8
+TT_Q_SPLIT3 = 16
+
+# Precision of the per-point MLP products (include/tt_abi.h, "precision of the matrix products"):
+#   "split3" (default)  fp32-grade: three fp16 pieces per operand, six product terms on the fp16 matrix pipe
+#   "f32"               every product on the fp32-input MFMA (the A/B reference)
+#   "split2"            the FAST mode: two pieces, three terms, ~2^-21.5 per product (tolerance-bounded)
+DEFAULT_PRECISION = "split3"
+_PRECISION_FLAGS = {"split3": (TT_R_SPLIT3, TT_Q_SPLIT3), "split2": (TT_R_SPLIT2, TT_Q_SPLIT2),
+                    "f32": (TT_R_EXACT_F32, TT_Q_EXACT_F32)}
+_PRECISION_ALIASES = {"fast": "split2", "exact_f32": "f32", "fp32_mfma": "f32"}
+
+
+def resolve_precision(precision: Optional[str] = None, exact_f32: bool = False) -> str:
+    """Canonical precision name.  `exact_f32=True` (the switch of rounds 2-4) means "f32"; naming both is an error
+    unless they agree."""
+    if precision is None:
+        return "f32" if exact_f32 else DEFAULT_PRECISION
+    name = _PRECISION_ALIASES.get(precision, precision)
+    if name not in _PRECISION_FLAGS:
+        raise ValueError(f"unknown precision {precision!r}: one of {sorted(_PRECISION_FLAGS)} / {sorted(_PRECISION_ALIASES)}")
+    if exact_f32 and name != "f32":
+        raise ValueError(f"exact_f32=True contradicts precision={precision!r}")
+    return name
+
+
+def r_flag(name: str) -> int:
+    return _PRECISION_FLAGS[name][0]
+
+
+def q_flag(name: str) -> int:
+    return _PRECISION_FLAGS[name][1]
 PLACEMENTS = {"tt": 0, "center": 1}  # enum tt_sample_placement
 
 

@@ -41,21 +41,33 @@ struct BwdGeoParams {
 #define GOFF_W2T (GOFF_W1T + IMG16_FLOATS(32, 64))
 #define LDS_GEO16_FLOATS (TT_BWD_WT_COPIES ? GOFF_W2T + IMG16_FLOATS(64, 64) : LDS_GEO_FLOATS)
 #define GEO_PAIR (TT_BWD_WT_COPIES ? PAIR_SEQ : PAIR_TR)
+// PREC_S3: the images of the third terms, appended (28 KB with the transposed copies: 157 KB per workgroup in all)
+#define GLO_W1 LDS_GEO16_FLOATS
+#define GLO_W2 (GLO_W1 + LO16_FLOATS(64, 32))
+#define GLO_W1T (GLO_W2 + LO16_FLOATS(64, 64))
+#define GLO_W2T (GLO_W1T + (TT_BWD_WT_COPIES ? LO16_FLOATS(32, 64) : 0))
+#define LDS_GEO3_FLOATS (GLO_W2T + (TT_BWD_WT_COPIES ? LO16_FLOATS(64, 64) : 0))
+template <int PREC>
+struct GeoWFloats {
+    static constexpr int value = PREC == PREC_S3 ? LDS_GEO3_FLOATS : LDS_GEO16_FLOATS;
+};
 
 // STATS: the work accounting (tt_render_cfg.stats) compiled in.  In this kernel even a never-taken scalar branch per
 // counting site costs 2-3 % (2.95 vs 2.85 ms: the branches cut hipcc's scheduling regions), so production launches
 // (stats == null) run the instantiation without it.
-template <bool EXACT, bool WG16, bool STATS = false>
+template <int PREC, bool WG16, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_GEO16_FLOATS + 4 * (GEO_SCRATCH_FLOATS + SCATTER_TAG_INTS)];
+    constexpr bool EXACT = PREC == PREC_F32;
+    constexpr int NT = PrecNT<PREC>::value, WF = GeoWFloats<PREC>::value;
+    __shared__ __attribute__((aligned(16))) float L[WF + 4 * (GEO_SCRATCH_FLOATS + SCATTER_TAG_INTS)];
     {
         MlpPtrs w = p.w;
-        stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
-        stage_weights<EXACT, 64, 64>(L + OFF_W2, w.w2);
+        stage_weights<PREC, 64, 32>(L + OFF_W1, L + GLO_W1, w.w1);
+        stage_weights<PREC, 64, 64>(L + OFF_W2, L + GLO_W2, w.w2);
         lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
         if (TT_BWD_WT_COPIES) {
-            stage_weights_t<EXACT, 64, 32>(L + GOFF_W1T, w.w1);
-            stage_weights_t<EXACT, 64, 64>(L + GOFF_W2T, w.w2);
+            stage_weights_t<PREC, 64, 32>(L + GOFF_W1T, L + GLO_W1T, w.w1);
+            stage_weights_t<PREC, 64, 64>(L + GOFF_W2T, L + GLO_W2T, w.w2);
         }
     }
     const tt_render_cfg& cfg = p.cfg;
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         const unsigned* bnd = reinterpret_cast<const unsigned*>(p.queue) + TT_SLOT_BOUNDS;
         const float Pm = __builtin_bit_cast(float, bnd[TT_BOUND_PLANES]), Sb = __builtin_bit_cast(float, bnd[TT_BOUND_UP0]),
                     Gb = __builtin_bit_cast(float, bnd[TT_BOUND_UP1]);
-        unsigned* word = reinterpret_cast<unsigned*>(L + LDS_GEO16_FLOATS);  // scratch is free until the main loop
+        unsigned* word = reinterpret_cast<unsigned*>(L + WF);  // scratch is free until the main loop
         const int t = threadIdx.x;
         float w1row = 0.f, a1col = 0.f, w3abs = 0.f;
         if (t < 64) {
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
     }
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5, wave_in_blk = threadIdx.x >> 6;
-    float* Xs = L + LDS_GEO16_FLOATS + wave_in_blk * (GEO_SCRATCH_FLOATS + SCATTER_TAG_INTS);
+    float* Xs = L + WF + wave_in_blk * (GEO_SCRATCH_FLOATS + SCATTER_TAG_INTS);
     float* Ys = Xs + 64 * XS;
     int* tags = reinterpret_cast<int*>(Ys + 64 * XS);
     scatter_init_tags(tags, lane);
@@ -183,10 +195,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
             // h1, h2 (and a1 under WG16) stay in RAW form: accumulators + a per-lane power-of-two factor (tt_mfma16.h,
             // "deferred factors"); their consumers are signs, the next product, and fmas that take the factor on the scalar
             float h1[32], h2[32], a2[32], a1[32], q[16], u1, u2;
-            mvx<EXACT, 64, 32, true>(L + OFF_W1, f, h1, i, hi, 1.f, &u1);
+            mvx<PREC, 64, 32, true>(L + OFF_W1, L + GLO_W1, f, h1, i, hi, 1.f, &u1);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mvx<EXACT, 64, 64, true>(L + OFF_W2, h1, h2, i, hi, u1, &u2);
+            mvx<PREC, 64, 64, true>(L + OFF_W2, L + GLO_W2, h1, h2, i, hi, u1, &u2);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
 #pragma unroll
@@ -196,33 +208,33 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
             }
             // a2 and a1 feed a product AND an outer product (dW2, dW1): split once under the per-launch scales
-            Split16<64, GEO_PAIR> a2s, a1s;  // (consumed by the transposed products and the outer-product staging)
+            Split16<64, GEO_PAIR, NT> a2s, a1s;  // (consumed by the transposed products and the outer-product staging)
             float ua1 = 1.f;                 // factor of a1 where it is RAW
             if (WG16) {
-                split16_vec<64, GEO_PAIR>(a2, sA2, a2s);
+                split16_vec<64, GEO_PAIR, NT>(a2, sA2, a2s);
 #if TT_BWD_WT_COPIES
-                mv16_pre<64, 64, true>(L + GOFF_W2T, a2s, 1.f / sA2, a1, i, hi, &ua1);
+                mv16_pre<64, 64, true, NT>(L + GOFF_W2T, a2s, 1.f / sA2, a1, i, hi, &ua1, L + GLO_W2T);
 #else
-                mv16t_pre<64, 64, 64>(L + OFF_W2, 0, a2s, 1.f / sA2, a1, lane);
+                mv16t_pre<64, 64, 64, NT>(L + OFF_W2, 0, a2s, 1.f / sA2, a1, lane, L + GLO_W2);
 #endif
             } else if constexpr (TT_BWD_WT_COPIES) {
-                mvtx_copy<EXACT, 64, 64, 64>(L + GOFF_W2T, L + OFF_W2, a2, a1, i, hi);
+                mvtx_copy<PREC, 64, 64, 64>(L + GOFF_W2T, L + GLO_W2T, L + OFF_W2, a2, a1, i, hi);
             } else {
-                mvtx<EXACT, 64, 64, 64>(L + OFF_W2, 0, a2, a1, i, hi);
+                mvtx<PREC, 64, 64, 64>(L + OFF_W2, L + GLO_W2, 0, a2, a1, i, hi);
             }
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
             if (WG16) {
-                split16_vec<64, GEO_PAIR>(a1, sA1 * ua1, a1s);
+                split16_vec<64, GEO_PAIR, NT>(a1, sA1 * ua1, a1s);
 #if TT_BWD_WT_COPIES
-                mv16_pre<32, 64>(L + GOFF_W1T, a1s, 1.f / sA1, q, i, hi);
+                mv16_pre<32, 64, false, NT>(L + GOFF_W1T, a1s, 1.f / sA1, q, i, hi, nullptr, L + GLO_W1T);
 #else
-                mv16t_pre<32, 64, 32>(L + OFF_W1, 0, a1s, 1.f / sA1, q, lane);
+                mv16t_pre<32, 64, 32, NT>(L + OFF_W1, 0, a1s, 1.f / sA1, q, lane, L + GLO_W1);
 #endif
             } else if constexpr (TT_BWD_WT_COPIES) {
-                mvtx_copy<EXACT, 32, 64, 32>(L + GOFF_W1T, L + OFF_W1, a1, q, i, hi);
+                mvtx_copy<PREC, 32, 64, 32>(L + GOFF_W1T, L + GLO_W1T, L + OFF_W1, a1, q, i, hi);
             } else {
-                mvtx<EXACT, 32, 64, 32>(L + OFF_W1, 0, a1, q, i, hi);
+                mvtx<PREC, 32, 64, 32>(L + OFF_W1, L + GLO_W1, 0, a1, q, i, hi);
             }
             TT_PHASE(3);
             // ---- network + plane gradients ----
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 TT_PHASE(7);
                 // a1bar = W1 qbar ; b1bar = m1 . a1bar ; v = sbar h1 + b1bar
                 float t1[32];
-                mvx<EXACT, 64, 32>(L + OFF_W1, qb, t1, i, hi);
+                mvx<PREC, 64, 32>(L + OFF_W1, L + GLO_W1, qb, t1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) t1[r] = h1[r] > 0.f ? t1[r] : 0.f;  // b1bar
                 float v[32];
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                 TT_PHASE(8);
                 // a2bar = W2 b1bar ; dw3 += sbar h2 + m2 . a2bar
                 float t2[32];
-                mvx<EXACT, 64, 64>(L + OFF_W2, t1, t2, i, hi);
+                mvx<PREC, 64, 64>(L + OFF_W2, L + GLO_W2, t1, t2, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) t2[r] = fmaf(sbar * u2, h2[r], h2[r] > 0.f ? t2[r] : 0.f);
                 stage_rows<64>(Xs, t2, i, hi);
@@ -340,27 +352,33 @@ static void launch_bwd_geo(const BwdGeoParams& p0, long long blocks, hipStream_t
 #else
     p.phase_cycles = nullptr;
 #endif
+    const int prec = tt_prec_of_r(p.cfg.flags);
+#define LAUNCH_GEO(PREC_, WG_)                                                                                        \
+    do {                                                                                                              \
+        if (p.cfg.stats)                                                                                              \
+            hipLaunchKernelGGL((k_decode_bwd_geo<PREC_, WG_, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);     \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_decode_bwd_geo<PREC_, WG_>), dim3((unsigned)blocks), dim3(256), 0, s, p);           \
+    } while (0)
     if (use_wg16(p.cfg)) {
         unsigned* bnd = reinterpret_cast<unsigned*>(p.queue) + TT_SLOT_BOUNDS;
         launch_planes_bound(p.packed, p.cfg, 0, bnd + TT_BOUND_PLANES, s);
         const long long n = p.cfg.n_rays * p.cfg.n_samples;  // upstream float4 (d sdf, d sdf_grad) per sample
         hipLaunchKernelGGL(k_absmax4, dim3(absmax_blocks(n), 1), dim3(256), 0, s, reinterpret_cast<const f32x4*>(p.ws), n, n,
                            bnd + TT_BOUND_UP0, bnd + TT_BOUND_UP1);
-        if (p.cfg.stats)
-            hipLaunchKernelGGL((k_decode_bwd_geo<false, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        if (prec == PREC_S3)
+            LAUNCH_GEO(PREC_S3, true);
         else
-            hipLaunchKernelGGL((k_decode_bwd_geo<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    } else if (p.cfg.flags & TT_R_EXACT_F32) {
-        if (p.cfg.stats)
-            hipLaunchKernelGGL((k_decode_bwd_geo<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL((k_decode_bwd_geo<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    } else {
-        if (p.cfg.stats)
-            hipLaunchKernelGGL((k_decode_bwd_geo<false, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL((k_decode_bwd_geo<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+            LAUNCH_GEO(PREC_S2, true);
+    } else if (prec == PREC_F32) {
+        LAUNCH_GEO(PREC_F32, false);
     }
+#ifdef TT_TUNING
+    else {  // TT_R_WGRAD_F32: the round-2 A/B kernel (two-piece products, fp32 outer products)
+        LAUNCH_GEO(PREC_S2, false);
+    }
+#endif
+#undef LAUNCH_GEO
 }
 int tt_launch_march_bwd(const float* rays_d, const float* t_starts, const float* t_ends, const tt_render_cfg* cfg,
                         const float* sdf, const float* sdf_grad, const float* features, const float* trans,

@@ -148,8 +148,8 @@ __device__ __forceinline__ void stage_rows16_sub(float* S, const float (&v)[TOT]
     for (int r = 0; r < N / 2; ++r) U[LIDX(r, hi) * XS + j] = wg16_pack(v[OFF + r] * sc);
 }
 // the same rows from a vector already split by split16_vec (tt_mfma16.h): one v_perm per staged dword
-template <int N, int PAIR>
-__device__ __forceinline__ void stage_rows16_pre(float* S, const Split16<N, PAIR>& v, int j, int hi) {
+template <int N, int PAIR, int NT>
+__device__ __forceinline__ void stage_rows16_pre(float* S, const Split16<N, PAIR, NT>& v, int j, int hi) {
     unsigned* U = reinterpret_cast<unsigned*>(S);
 #pragma unroll
     for (int t = 0; t < N / 4; ++t) {  // dword t of the split holds registers pair_reg<PAIR>(t, 0 / 1)
@@ -234,8 +234,8 @@ __device__ __forceinline__ void frag_store(half_t* img_h, half_t* img_l, int ks,
     *reinterpret_cast<h8_t*>(img_l + (ks * 2 + hi) * FR_BLK + j * 8) = f.l;
 }
 // all k-steps of a split vector (this lane: sample i, half-wave hi)
-template <int N, int PAIR>
-__device__ __forceinline__ void frag_image_store(half_t* img_h, half_t* img_l, const Split16<N, PAIR>& v, int i, int hi) {
+template <int N, int PAIR, int NT>
+__device__ __forceinline__ void frag_image_store(half_t* img_h, half_t* img_l, const Split16<N, PAIR, NT>& v, int i, int hi) {
 #pragma unroll
     for (int s = 0; s < N / 16; ++s) {
         *reinterpret_cast<u4_t*>(img_h + (s * 2 + hi) * FR_BLK + i * 8) = u4_t{v.h[4 * s], v.h[4 * s + 1], v.h[4 * s + 2], v.h[4 * s + 3]};
@@ -725,7 +725,19 @@ struct BwdTexParams {
 #define TV1T TEX_W_FLOATS
 #define TV2T (TV1T + IMG16_FLOATS(96, 64))
 #define TEX_W16_FLOATS (TT_BWD_WT_COPIES ? TV2T + IMG16_FLOATS(64, 64) : TEX_W_FLOATS)
-void tt_launch_bwd_tex2(const BwdTexParams& p, int cus, hipStream_t s);  // tt_backward_tex2.hip
+// PREC_S3 (three-piece products): the images of the third terms follow V3, and there are NO transposed copies -- with them
+// the kernel would need 204 KB of LDS -- so the V2^T / V1^T products read the forward images through ds_read_b64_tr_b16
+// (mv16t, as the forward kernels do): 66 KB of images + 76 KB of per-wave scratch = 143 KB.
+#define TLO_V1 TEX_W_FLOATS
+#define TLO_V2 (TLO_V1 + LO16_FLOATS(64, 96))
+#define TEX_W3P_FLOATS (TLO_V2 + LO16_FLOATS(64, 64))
+template <int PREC>
+struct TexWFloats {
+    static constexpr int value = PREC == PREC_S3 ? TEX_W3P_FLOATS : TEX_W16_FLOATS;
+};
+#ifdef TT_TUNING
+void tt_launch_bwd_tex2(const BwdTexParams& p, int cus, hipStream_t s);  // tt_backward_tex2.hip (tuning build only)
+#endif
 
 // =====================================================================================================
 // host side
@@ -845,6 +857,8 @@ static inline void launch_planes_bound(const float* packed, const tt_render_cfg&
                        (unsigned*)nullptr);
 }
 
+// outer products on the fp16 pipe: both split modes (the fp32 MFMA mode and the tuning build's TT_R_WGRAD_F32 A/B kernel
+// use fp32 outer products)
 static inline bool use_wg16(const tt_render_cfg& cfg) { return !(cfg.flags & (TT_R_EXACT_F32 | TT_R_WGRAD_F32)); }
 
 static inline int points_cfg(tt_render_cfg* c, int32_t n_batch, int64_t n_points, int32_t n_prompts,
@@ -866,7 +880,8 @@ static inline int points_cfg(tt_render_cfg* c, int32_t n_batch, int64_t n_points
     c->stats = nullptr;
     c->cos_anneal_ratio = 1.f;
     c->rgb_grad_shrink = 1.f;
-    c->flags = (q_flags & TT_Q_EXACT_F32) ? TT_R_EXACT_F32 : 0;
+    if (!tt_qflags_ok(q_flags)) return TT_ERR_BAD_ARG;
+    c->flags = (q_flags & TT_Q_EXACT_F32) ? TT_R_EXACT_F32 : ((q_flags & TT_Q_SPLIT2) ? TT_R_SPLIT2 : 0);
     c->image_w = 0;
     c->tile_sb = 1;
     c->tile_chunk = 0;

@@ -8,17 +8,20 @@
 #define TEX_SCRATCH_FLOATS (128 * XS)
 
 // STATS: work accounting compiled in (see k_decode_bwd_geo): production launches run the instantiation without it
-template <bool EXACT, bool WG16, bool STATS = false>
+template <int PREC, bool WG16, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
-    __shared__ __attribute__((aligned(16))) float Lt[TEX_W16_FLOATS + 4 * (TEX_SCRATCH_FLOATS + SCATTER_TAG_INTS)];
+    constexpr bool EXACT = PREC == PREC_F32;
+    constexpr bool COPIES = TT_BWD_WT_COPIES && PREC != PREC_S3;  // transposed weight copies (tt_backward_common.h)
+    constexpr int NT = PrecNT<PREC>::value, WF = TexWFloats<PREC>::value;
+    __shared__ __attribute__((aligned(16))) float Lt[WF + 4 * (TEX_SCRATCH_FLOATS + SCATTER_TAG_INTS)];
     {
         MlpPtrs w = p.w;
-        stage_weights<EXACT, 64, 96>(Lt + TV1, w.v1);
-        stage_weights<EXACT, 64, 64>(Lt + TV2, w.v2);
+        stage_weights<PREC, 64, 96>(Lt + TV1, Lt + TLO_V1, w.v1);
+        stage_weights<PREC, 64, 64>(Lt + TV2, Lt + TLO_V2, w.v2);
         lds_load_matrix(Lt + TV3, w.v3, 3, 64, 64);
-        if (TT_BWD_WT_COPIES) {
-            stage_weights_t<EXACT, 64, 96>(Lt + TV1T, w.v1);
-            stage_weights_t<EXACT, 64, 64>(Lt + TV2T, w.v2);
+        if constexpr (COPIES) {
+            stage_weights_t<PREC, 64, 96>(Lt + TV1T, nullptr, w.v1);
+            stage_weights_t<PREC, 64, 64>(Lt + TV2T, nullptr, w.v2);
         }
     }
     const tt_render_cfg& cfg = p.cfg;
@@ -31,7 +34,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         const unsigned* bnd = reinterpret_cast<const unsigned*>(p.queue) + TT_SLOT_BOUNDS;
         const float Pm = __builtin_bit_cast(float, bnd[TT_BOUND_PLANES]), Gr = __builtin_bit_cast(float, bnd[TT_BOUND_UP0]),
                     Gf = __builtin_bit_cast(float, bnd[TT_BOUND_UP1]);
-        unsigned* word = reinterpret_cast<unsigned*>(Lt + TEX_W16_FLOATS);  // scratch is free until the main loop
+        unsigned* word = reinterpret_cast<unsigned*>(Lt + WF);  // scratch is free until the main loop
         const int t = threadIdx.x;
         const float CBmax = __builtin_fabsf(cfg.rgb_grad_shrink) * (1.002f * 0.25f) * Gr + Gf;
         float v1row = 0.f, k2b = 0.f, kb1 = 0.f;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5, wave_in_blk = threadIdx.x >> 6;
     // per-wave scratch: rows 0..31 = Xs (transposition window / first half of bigger operands), rows 32..127 = Ys
-    float* Xs = Lt + TEX_W16_FLOATS + wave_in_blk * (TEX_SCRATCH_FLOATS + SCATTER_TAG_INTS);
+    float* Xs = Lt + WF + wave_in_blk * (TEX_SCRATCH_FLOATS + SCATTER_TAG_INTS);
     float* Ys = Xs + 32 * XS;  // 96 rows: the parked e
     int* tags = reinterpret_cast<int*>(Xs + 128 * XS);
     // cbar of the tile, [3][32]: in the 4 pad columns of Xs rows 0..23 (row r holds floats 4r..4r+3 of the 96) --
@@ -180,25 +183,25 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         const bool do_wgrad = region_w && !TT_DBG(cfg.flags, TT_DBG_NO_WGRAD);
         float k1[32], k2[32];
         if (WG16) {  // e is split once, under its per-launch scale, for the outer product and for V1 e
-            Split16<96> es;
-            split16_vec<96>(e, sE, es);
+            Split16<96, PAIR_SEQ, NT> es;
+            split16_vec<96, PAIR_SEQ, NT>(e, sE, es);
             if (do_wgrad) stage_rows16_pre<96>(Ys, es, i, hi);
             TT_PHASE(2);
-            mv16_pre<64, 96>(Lt + TV1, es, 1.f / sE, k1, i, hi);
+            mv16_pre<64, 96, false, NT>(Lt + TV1, es, 1.f / sE, k1, i, hi, nullptr, Lt + TLO_V1);
         } else {
             if (do_wgrad) stage_rows<96>(Ys, e, i, hi);
             TT_PHASE(2);
-            mvx<EXACT, 64, 96>(Lt + TV1, e, k1, i, hi);
+            mvx<PREC, 64, 96>(Lt + TV1, Lt + TLO_V1, e, k1, i, hi);
         }
 #pragma unroll
         for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
         TT_PHASE(3);
-        Split16<64> k1s;  // k1 likewise: V2 k1 now, the dV2 outer product later
+        Split16<64, PAIR_SEQ, NT> k1s;  // k1 likewise: V2 k1 now, the dV2 outer product later
         if (WG16) {
-            split16_vec<64>(k1, sK1, k1s);
-            mv16_pre<64, 64>(Lt + TV2, k1s, 1.f / sK1, k2, i, hi);
+            split16_vec<64, PAIR_SEQ, NT>(k1, sK1, k1s);
+            mv16_pre<64, 64, false, NT>(Lt + TV2, k1s, 1.f / sK1, k2, i, hi, nullptr, Lt + TLO_V2);
         } else {
-            mvx<EXACT, 64, 64>(Lt + TV2, k1, k2, i, hi);
+            mvx<PREC, 64, 64>(Lt + TV2, Lt + TLO_V2, k1, k2, i, hi);
         }
 #pragma unroll
         for (int r = 0; r < 32; ++r) k2[r] = fmaxf(k2[r], 0.f);
@@ -242,10 +245,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         }
         // ---- k1bar = n1 . (V2^T k2bar) ----
         float kb1[32];
-        if constexpr (TT_BWD_WT_COPIES)
-            mvtx_copy<EXACT, 64, 64, 64>(Lt + TV2T, Lt + TV2, k2, kb1, i, hi);
+        if constexpr (COPIES)
+            mvtx_copy<PREC, 64, 64, 64>(Lt + TV2T, nullptr, Lt + TV2, k2, kb1, i, hi);
         else
-            mvtx<EXACT, 64, 64, 64>(Lt + TV2, 0, k2, kb1, i, hi);
+            mvtx<PREC, 64, 64, 64>(Lt + TV2, Lt + TLO_V2, 0, k2, kb1, i, hi);
 #pragma unroll
         for (int r = 0; r < 32; ++r) kb1[r] = k1[r] > 0.f ? kb1[r] : 0.f;
         TT_PHASE(6);
@@ -295,10 +298,10 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
             scatter_clear<SC_EXACT>(M, lane);
             // ebar = V1^T k1bar for the three planes in ONE product (96 rows: k1bar is split into fp16 terms once)
             float eb[48];
-            if constexpr (TT_BWD_WT_COPIES)
-                mvtx_copy<EXACT, 96, 64, 96>(Lt + TV1T, Lt + TV1, kb1, eb, i, hi);
+            if constexpr (COPIES)
+                mvtx_copy<PREC, 96, 64, 96>(Lt + TV1T, nullptr, Lt + TV1, kb1, eb, i, hi);
             else
-                mvtx<EXACT, 96, 64, 96>(Lt + TV1, 0, kb1, eb, i, hi);
+                mvtx<PREC, 96, 64, 96>(Lt + TV1, Lt + TLO_V1, 0, kb1, eb, i, hi);
             TT_PHASE(9);
             const int tex0 = (int)(pofs / TT_C);
             scatter_planes<SC_EXACT>(grad_out, grad_bytes, Es, M, tags, Es + 32 * 33, i, hi, [&](int pl, PlaneRefs& refs) {
@@ -362,6 +365,14 @@ static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t
 #else
     p.phase_cycles = nullptr;
 #endif
+    const int prec = tt_prec_of_r(p.cfg.flags);
+#define LAUNCH_TEX(PREC_, WG_)                                                                                        \
+    do {                                                                                                              \
+        if (p.cfg.stats)                                                                                              \
+            hipLaunchKernelGGL((k_decode_bwd_tex<PREC_, WG_, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);     \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_decode_bwd_tex<PREC_, WG_>), dim3((unsigned)blocks), dim3(256), 0, s, p);           \
+    } while (0)
     if (use_wg16(p.cfg)) {
         unsigned* bnd = reinterpret_cast<unsigned*>(p.queue) + TT_SLOT_BOUNDS;
         launch_planes_bound(p.packed, p.cfg, 3, bnd + TT_BOUND_PLANES, s);  // (p.packed may be slid by 3 planes: points)
@@ -372,26 +383,27 @@ static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t
             const long long n = p.cfg.n_rays * p.cfg.n_samples * 3;
             hipLaunchKernelGGL(k_absmax1, dim3(absmax_blocks(n)), dim3(256), 0, s, p.g_features, n, bnd + TT_BOUND_UP1);
         }
-        // render path, default precision: the wave-pair kernel (tt_backward_tex2.hip: two waves per SIMD) when the caller asks
-        // for it (TT_R_BWD_PAIR: opt-in while it is slower than the one-wave-per-tile kernel); the
-        // per-point variant (no march weights) always runs the latter
-        if (p.weights && (p.cfg.flags & TT_R_BWD_PAIR) && !(p.cfg.flags & TT_R_BWD_SOLO))
+#ifdef TT_TUNING
+        // tuning build only: the experimental wave-pair kernel of round 4 (tt_backward_tex2.hip: two waves per SIMD; correct,
+        // 1.4x slower than the one-wave-per-tile kernel), two-piece mode, render path
+        if (p.weights && prec == PREC_S2 && (p.cfg.flags & TT_R_BWD_PAIR) && !(p.cfg.flags & TT_R_BWD_SOLO)) {
             tt_launch_bwd_tex2(p, tt_num_cus(), s);
-        else if (p.cfg.stats)
-            hipLaunchKernelGGL((k_decode_bwd_tex<false, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+            return;
+        }
+#endif
+        if (prec == PREC_S3)
+            LAUNCH_TEX(PREC_S3, true);
         else
-            hipLaunchKernelGGL((k_decode_bwd_tex<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    } else if (p.cfg.flags & TT_R_EXACT_F32) {
-        if (p.cfg.stats)
-            hipLaunchKernelGGL((k_decode_bwd_tex<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL((k_decode_bwd_tex<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    } else {
-        if (p.cfg.stats)
-            hipLaunchKernelGGL((k_decode_bwd_tex<false, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL((k_decode_bwd_tex<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+            LAUNCH_TEX(PREC_S2, true);
+    } else if (prec == PREC_F32) {
+        LAUNCH_TEX(PREC_F32, false);
     }
+#ifdef TT_TUNING
+    else {  // TT_R_WGRAD_F32: the round-2 A/B kernel
+        LAUNCH_TEX(PREC_S2, false);
+    }
+#endif
+#undef LAUNCH_TEX
 }
 
 extern "C" int tt_render_bwd_tex(const float* packed, const tt_mlp_weights* w, const float* rays_o,

@@ -29,6 +29,8 @@
 // scratch and the accumulators are reloaded around the scatter; and a pair hand-off costs ~740 cycles of flag ping-pong
 // (tools/pair_sync_probe.hip), six times per tile step.  What a faster version needs is listed in DESIGN.md ("wave
 // pairs"): a <= 150-register non-accumulator body and fewer, coarser hand-offs.
+// TUNING BUILD ONLY since round 5 (-DTT_TUNING, libtt_hip_tuning.so): the product library carries ONE texture-backward kernel.
+#ifdef TT_TUNING
 #include "tt_backward_common.h"
 
 #ifndef P2_PAIRS
@@ -95,7 +97,7 @@ __device__ __forceinline__ void pair_sync(PairCtx& pc, int lane) {
     while (__builtin_amdgcn_readfirstlane(
                __hip_atomic_load(pc.ctrl + (pc.H ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < pc.seq) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 20)) break;
+        if (++spins > (1 << 20)) __builtin_trap();  // a lost partner is a bug: fault the launch, never continue on half-written fragments
     }
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     __builtin_amdgcn_sched_barrier(0);
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(P2_THREADS, 2) void k_decode_bwd_tex2(BwdTexParams 
     __shared__ __attribute__((aligned(16))) float Lt[TEX_W_FLOATS + P2_PAIRS * P2_PAIR_FLOATS];
     {
         MlpPtrs w = p.w;
-        stage_weights<false, 64, 96>(Lt + TV1, w.v1);
-        stage_weights<false, 64, 64>(Lt + TV2, w.v2);
+        stage_weights<PREC_S2, 64, 96>(Lt + TV1, nullptr, w.v1);
+        stage_weights<PREC_S2, 64, 64>(Lt + TV2, nullptr, w.v2);
         lds_load_matrix(Lt + TV3, w.v3, 3, 64, 64);
     }
     const tt_render_cfg& cfg = p.cfg;
@@ -697,3 +699,5 @@ void tt_launch_bwd_tex2(const BwdTexParams& p, int cus, hipStream_t s) {
     blocks = (blocks + 7) / 8 * 8;
     hipLaunchKernelGGL(k_decode_bwd_tex2, dim3((unsigned)blocks), dim3(P2_THREADS), 0, s, p);
 }
+
+#endif  // TT_TUNING

@@ -145,10 +145,9 @@ struct DecodeCfg {
 // outputs are identical in both half-waves.  gq = J^T q (WITHOUT the sphere term).
 // the weight images in L are split-fp16 images (tt_mfma16.h); the W2^T / W1^T products of the normal chain read the SAME
 // images through transposed LDS reads (mv16t) -- rounds 1-3 kept 26 KB of transposed copies here
-#define LDS_W16_FLOATS LDS_W_FLOATS
 
 // texture half: e -> feature net -> c (3 raw features).  Lanes with !valid gather nothing (their c is 0).
-template <bool EXACT>
+template <int PREC>
 __device__ __forceinline__ void decode_tex_fwd(const float* L, const DecodeCfg& dc, float X, float Y, float Z,
                                                bool valid, int i, int hi, float (&c)[3]) {
     c[0] = c[1] = c[2] = 0.f;
@@ -163,10 +162,10 @@ __device__ __forceinline__ void decode_tex_fwd(const float* L, const DecodeCfg& 
         // hidden vectors stay in RAW form (accumulators + a per-lane power-of-two factor, tt_mfma16.h): ReLU and the next
         // product's normalisation do not care, the factor is applied once to the three outputs
         float k1[32], k2[32], u1, u2;
-        mvx<EXACT, 64, 96, true>(L + OFF_V1, e, k1, i, hi, 1.f, &u1);
+        mvx<PREC, 64, 96, true>(L + OFF_V1, L + LO_V1, e, k1, i, hi, 1.f, &u1);
 #pragma unroll
         for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
-        mvx<EXACT, 64, 64, true>(L + OFF_V2, k1, k2, i, hi, u1, &u2);
+        mvx<PREC, 64, 64, true>(L + OFF_V2, L + LO_V2, k1, k2, i, hi, u1, &u2);
 #pragma unroll
         for (int r = 0; r < 32; ++r) k2[r] = fmaxf(k2[r], 0.f);
 #pragma unroll
@@ -175,7 +174,7 @@ __device__ __forceinline__ void decode_tex_fwd(const float* L, const DecodeCfg& 
 }
 
 // geometry half: f (+ J) -> sdf net -> s0 and, if NEED_N, gq = J^T q (WITHOUT the sphere term)
-template <bool NEED_N, bool EXACT>
+template <bool NEED_N, int PREC>
 __device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& dc, float X, float Y, float Z,
                                                bool valid, int i, int hi, float& s0, float (&gq)[3]) {
     s0 = 0.f;
@@ -199,10 +198,10 @@ __device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& 
     } else if (__any(any)) {
         tile_stat(dc.st, TT_STAT_EXECUTED);
         float h1[32], h2[32], u1, u2;  // RAW hidden vectors (see decode_tex_fwd): only their signs and the dot product matter
-        mvx<EXACT, 64, 32, true>(L + OFF_W1, f, h1, i, hi, 1.f, &u1);
+        mvx<PREC, 64, 32, true>(L + OFF_W1, L + LO_W1, f, h1, i, hi, 1.f, &u1);
 #pragma unroll
         for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-        mvx<EXACT, 64, 64, true>(L + OFF_W2, h1, h2, i, hi, u1, &u2);
+        mvx<PREC, 64, 64, true>(L + OFF_W2, L + LO_W2, h1, h2, i, hi, u1, &u2);
 #pragma unroll
         for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
         s0 = dot_lds<64>(L + OFF_W3, h2, hi) * u2;
@@ -216,10 +215,10 @@ __device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& 
                 for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
             }
             float ua1;
-            mvtx<EXACT, 64, 64, 64, true>(L + OFF_W2, 0, a2, a1, i, hi, 1.f, &ua1);
+            mvtx<PREC, 64, 64, 64, true>(L + OFF_W2, L + LO_W2, 0, a2, a1, i, hi, 1.f, &ua1);
 #pragma unroll
             for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-            mvtx<EXACT, 32, 64, 32>(L + OFF_W1, 0, a1, q, i, hi, ua1);
+            mvtx<PREC, 32, 64, 32>(L + OFF_W1, L + LO_W1, 0, a1, q, i, hi, ua1);
             float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -234,13 +233,13 @@ __device__ __forceinline__ void decode_geo_fwd(const float* L, const DecodeCfg& 
     }
 }
 
-template <bool NEED_N, bool NEED_TEX, bool EXACT>
+template <bool NEED_N, bool NEED_TEX, int PREC>
 __device__ __forceinline__ void decode_fwd(const float* L, const DecodeCfg& dc, float px, float py, float pz,
                                            bool valid, int i, int hi, float& s0, float (&gq)[3], float (&c)[3]) {
     const float X = scale_coord(px, dc.radius), Y = scale_coord(py, dc.radius), Z = scale_coord(pz, dc.radius);
     c[0] = c[1] = c[2] = 0.f;
-    if (NEED_TEX) decode_tex_fwd<EXACT>(L, dc, X, Y, Z, valid, i, hi, c);
-    decode_geo_fwd<NEED_N, EXACT>(L, dc, X, Y, Z, valid, i, hi, s0, gq);
+    if (NEED_TEX) decode_tex_fwd<PREC>(L, dc, X, Y, Z, valid, i, hi, c);
+    decode_geo_fwd<NEED_N, PREC>(L, dc, X, Y, Z, valid, i, hi, s0, gq);
 }
 
 // =====================================================================================================
@@ -261,14 +260,14 @@ struct QueryParams {
 };
 
 // weight images of the forward decode kernels: split-fp16 (tt_mfma16.h)
-template <bool NEED_N, bool NEED_TEX, bool EXACT>
+template <bool NEED_N, bool NEED_TEX, int PREC>
 __device__ __forceinline__ void stage_decode_images(float* L, const MlpPtrs& w) {
-    stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
-    stage_weights<EXACT, 64, 64>(L + OFF_W2, w.w2);
+    stage_weights<PREC, 64, 32>(L + OFF_W1, L + LO_W1, w.w1);
+    stage_weights<PREC, 64, 64>(L + OFF_W2, L + LO_W2, w.w2);
     lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
     if (NEED_TEX) {
-        stage_weights<EXACT, 64, 96>(L + OFF_V1, w.v1);
-        stage_weights<EXACT, 64, 64>(L + OFF_V2, w.v2);
+        stage_weights<PREC, 64, 96>(L + OFF_V1, L + LO_V1, w.v1);
+        stage_weights<PREC, 64, 64>(L + OFF_V2, L + LO_V2, w.v2);
         lds_load_matrix(L + OFF_V3, w.v3, 3, 64, 64);
     }
 }
@@ -278,11 +277,11 @@ __device__ __forceinline__ void stage_decode_images(float* L, const MlpPtrs& w) 
 #define DECODE_THREADS 512
 #endif
 
-template <bool NEED_N, bool NEED_TEX, bool EXACT>
+template <bool NEED_N, bool NEED_TEX, int PREC>
 __global__ __launch_bounds__(DECODE_THREADS) void k_query_points(QueryParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS + (DECODE_THREADS / 64) * GC_SCRATCH_FLOATS];
-    float* T = L + LDS_W16_FLOATS + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
-    stage_decode_images<NEED_N, NEED_TEX, EXACT>(L, p.w);
+    __shared__ __attribute__((aligned(16))) float L[FwdWFloats<PREC>::value + (DECODE_THREADS / 64) * GC_SCRATCH_FLOATS];
+    float* T = L + FwdWFloats<PREC>::value + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
+    stage_decode_images<NEED_N, NEED_TEX, PREC>(L, p.w);
     __syncthreads();
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const long long tiles_per_batch = (p.n_points + TT_TILE - 1) / TT_TILE;
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_query_points(QueryParams p) 
         dc.dbg = 0;
         const float px = p.points[idx * 3 + 0], py = p.points[idx * 3 + 1], pz = p.points[idx * 3 + 2];
         float s0, gq[3], c[3];
-        decode_fwd<NEED_N, NEED_TEX, EXACT>(L, dc, px, py, pz, valid, i, hi, s0, gq, c);
+        decode_fwd<NEED_N, NEED_TEX, PREC>(L, dc, px, py, pz, valid, i, hi, s0, gq, c);
         float nrm;
         const float sdf = s0 + sphere_bias(px, py, pz, p.bias_radius, nrm);
         if (valid && hi == 0) {
@@ -334,6 +333,16 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_query_points(QueryParams p) 
 #define OFF_D2 (OFF_D1 + 64 * W1S)
 #define OFF_D3 (OFF_D2 + 64 * W2S)
 #define LDS_FIELD_FLOATS (OFF_D3 + 3 * 64)
+// third-term images (PREC_S3), appended
+#define LO_FW1 LDS_FIELD_FLOATS
+#define LO_FW2 (LO_FW1 + LO16_FLOATS(64, 32))
+#define LO_D1 (LO_FW2 + LO16_FLOATS(64, 64))
+#define LO_D2 (LO_D1 + LO16_FLOATS(64, 32))
+#define LDS_FIELD3_FLOATS (LO_D2 + LO16_FLOATS(64, 64))
+template <int PREC>
+struct FieldWFloats {
+    static constexpr int value = PREC == PREC_S3 ? LDS_FIELD3_FLOATS : LDS_FIELD_FLOATS;
+};
 
 struct QueryFieldParams {
     const float* packed;
@@ -348,17 +357,18 @@ struct QueryFieldParams {
     float* out_def;
 };
 
-template <bool EXACT>
-__global__ __launch_bounds__(256, 2) void k_query_field(QueryFieldParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_FIELD_FLOATS + 4 * GC_SCRATCH_FLOATS];
-    float* T = L + LDS_FIELD_FLOATS + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
+template <int PREC>
+// (two 4-wave workgroups per CU: 81 KB each; one under PREC_S3: 110 KB)
+__global__ __launch_bounds__(256, PREC == PREC_S3 ? 1 : 2) void k_query_field(QueryFieldParams p) {
+    __shared__ __attribute__((aligned(16))) float L[FieldWFloats<PREC>::value + 4 * GC_SCRATCH_FLOATS];
+    float* T = L + FieldWFloats<PREC>::value + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
     {  // split-fp16 images (tt_mfma16.h), same footprint as the fp32 ones
         MlpPtrs w = p.w;
-        stage_weights<EXACT, 64, 32>(L + OFF_W1, w.w1);
-        stage_weights<EXACT, 64, 64>(L + OFF_W2, w.w2);
+        stage_weights<PREC, 64, 32>(L + OFF_W1, L + LO_FW1, w.w1);
+        stage_weights<PREC, 64, 64>(L + OFF_W2, L + LO_FW2, w.w2);
         lds_load_matrix(L + OFF_W3, w.w3, 1, 64, 64);
-        stage_weights<EXACT, 64, 32>(L + OFF_D1, w.v1);
-        stage_weights<EXACT, 64, 64>(L + OFF_D2, w.v2);
+        stage_weights<PREC, 64, 32>(L + OFF_D1, L + LO_D1, w.v1);
+        stage_weights<PREC, 64, 64>(L + OFF_D2, L + LO_D2, w.v2);
         lds_load_matrix(L + OFF_D3, w.v3, 3, 64, 64);
     }
     __syncthreads();
@@ -383,17 +393,17 @@ __global__ __launch_bounds__(256, 2) void k_query_field(QueryFieldParams p) {
         float s0 = 0.f, d[3] = {0.f, 0.f, 0.f};
         if (any) {  // exact skip otherwise: bias-free MLPs of a zero vector
             float h1[32], h2[32];
-            mvx<EXACT, 64, 32>(L + OFF_W1, f, h1, i, hi);
+            mvx<PREC, 64, 32>(L + OFF_W1, L + LO_FW1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mvx<EXACT, 64, 64>(L + OFF_W2, h1, h2, i, hi);
+            mvx<PREC, 64, 64>(L + OFF_W2, L + LO_FW2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
             s0 = dot_lds<64>(L + OFF_W3, h2, hi);
-            mvx<EXACT, 64, 32>(L + OFF_D1, f, h1, i, hi);
+            mvx<PREC, 64, 32>(L + OFF_D1, L + LO_D1, f, h1, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-            mvx<EXACT, 64, 64>(L + OFF_D2, h1, h2, i, hi);
+            mvx<PREC, 64, 64>(L + OFF_D2, L + LO_D2, h1, h2, i, hi);
 #pragma unroll
             for (int r = 0; r < 32; ++r) h2[r] = fmaxf(h2[r], 0.f);
 #pragma unroll
@@ -429,11 +439,11 @@ struct DecodeRaysParams {
     float* features;
 };
 
-template <bool NEED_N, bool NEED_TEX, bool EXACT>
+template <bool NEED_N, bool NEED_TEX, int PREC>
 __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS + (DECODE_THREADS / 64) * GC_SCRATCH_FLOATS];
-    float* T = L + LDS_W16_FLOATS + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
-    stage_decode_images<NEED_N, NEED_TEX, EXACT>(L, p.w);
+    __shared__ __attribute__((aligned(16))) float L[FwdWFloats<PREC>::value + (DECODE_THREADS / 64) * GC_SCRATCH_FLOATS];
+    float* T = L + FwdWFloats<PREC>::value + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
+    stage_decode_images<NEED_N, NEED_TEX, PREC>(L, p.w);
     __syncthreads();
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
             float tm, px, py, pz;
             sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
             float s0, gq[3], c[3];
-            decode_fwd<NEED_N, NEED_TEX, EXACT>(L, dc, px, py, pz, rvalid, i, hi, s0, gq, c);
+            decode_fwd<NEED_N, NEED_TEX, PREC>(L, dc, px, py, pz, rvalid, i, hi, s0, gq, c);
             float nrm;
             const float sdf = s0 + sphere_bias(px, py, pz, cfg.sdf_bias_radius, nrm);
             if (rvalid && hi == 0 && !TT_DBG(cfg.flags, TT_DBG_NO_STORE)) {
@@ -549,11 +559,11 @@ struct RenderEvalParams {
     unsigned long long* stats;  // [0] += tile steps decoded, [1] += tile steps with a texture decode (may be null)
 };
 
-template <bool EXACT>
+template <int PREC>
 __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams p) {
-    __shared__ __attribute__((aligned(16))) float L[LDS_W16_FLOATS + (DECODE_THREADS / 64) * GC_SCRATCH_FLOATS];
-    float* T = L + LDS_W16_FLOATS + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
-    stage_decode_images<true, true, EXACT>(L, p.w);
+    __shared__ __attribute__((aligned(16))) float L[FwdWFloats<PREC>::value + (DECODE_THREADS / 64) * GC_SCRATCH_FLOATS];
+    float* T = L + FwdWFloats<PREC>::value + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
+    stage_decode_images<true, true, PREC>(L, p.w);
     __syncthreads();
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
@@ -597,7 +607,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
             const float livef = ray_okf * (T < p.eps_T ? 0.f : 1.f);
             const bool live = livef != 0.f;
             float s0, gq[3];
-            decode_geo_fwd<true, EXACT>(L, dc, X, Y, Z, live, i, hi, s0, gq);
+            decode_geo_fwd<true, PREC>(L, dc, X, Y, Z, live, i, hi, s0, gq);
             ++n_geo;
             float nrm;
             const float sdf = s0 + sphere_bias(px, py, pz, cfg.sdf_bias_radius, nrm);
@@ -622,7 +632,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
             const bool want_tex = wgt > p.eps_w;
             if (__any(want_tex)) {
                 float c[3];
-                decode_tex_fwd<EXACT>(L, dc, X, Y, Z, want_tex, i, hi, c);
+                decode_tex_fwd<PREC>(L, dc, X, Y, Z, want_tex, i, hi, c);
                 ++n_tex;
                 if (want_tex) {  // NoMaterial + sigmoid-mipnerf (no_material.py:41-54, ops.py:118-119)
                     cr = fmaf(wgt, sigmoid_(c[0]) * 1.002f - 0.001f, cr);
@@ -707,7 +717,7 @@ extern "C" int tt_query_points(const float* packed, const tt_mlp_weights* w, con
                                float* out_sdf_grad, float* out_features, void* stream) {
     if (!packed || !w || !points || n_batch <= 0 || n_points <= 0 || n_prompts <= 0 || views_per_prompt <= 0)
         return TT_ERR_BAD_ARG;
-    if (n_batch != n_prompts * views_per_prompt || !(radius > 0.f)) return TT_ERR_BAD_ARG;
+    if (n_batch != n_prompts * views_per_prompt || !(radius > 0.f) || !tt_qflags_ok(flags)) return TT_ERR_BAD_ARG;
     if (plane_h != plane_w || plane_h <= 0) return TT_ERR_UNSUPPORTED;
     const bool need_n = (flags & TT_Q_NORMAL) != 0, need_t = (flags & TT_Q_TEX) != 0;
     if (!w->w1 || !w->w2 || !w->w3 || (need_t && (!w->v1 || !w->v2 || !w->v3))) return TT_ERR_BAD_ARG;
@@ -732,13 +742,15 @@ extern "C" int tt_query_points(const float* packed, const tt_mlp_weights* w, con
     if (blocks > cus) blocks = cus;
     dim3 grid((unsigned)blocks), block(DECODE_THREADS);
     hipStream_t s = (hipStream_t)stream;
-    const bool exact = (flags & TT_Q_EXACT_F32) != 0;
+    const int prec = tt_prec_of_q(flags);
 #define LAUNCH_QP(N, T)                                                                        \
     do {                                                                                       \
-        if (exact)                                                                             \
-            hipLaunchKernelGGL((k_query_points<N, T, true>), grid, block, 0, s, p);            \
+        if (prec == PREC_F32)                                                                  \
+            hipLaunchKernelGGL((k_query_points<N, T, PREC_F32>), grid, block, 0, s, p);        \
+        else if (prec == PREC_S3)                                                              \
+            hipLaunchKernelGGL((k_query_points<N, T, PREC_S3>), grid, block, 0, s, p);         \
         else                                                                                   \
-            hipLaunchKernelGGL((k_query_points<N, T, false>), grid, block, 0, s, p);           \
+            hipLaunchKernelGGL((k_query_points<N, T, PREC_S2>), grid, block, 0, s, p);         \
     } while (0)
     if (need_n && need_t)
         LAUNCH_QP(true, true);
@@ -767,6 +779,13 @@ int tt_validate_cfg(const tt_render_cfg* cfg) {
     if (tt_planes_too_large(cfg->n_prompts, cfg->plane_h, cfg->plane_w)) return TT_ERR_UNSUPPORTED;
     if (!(cfg->radius > 0.f) || (!cfg->inv_std_dev && !(cfg->inv_std > 0.f))) return TT_ERR_BAD_ARG;
     if (cfg->flags < 0) return TT_ERR_BAD_ARG;  // (the kernels use `flags >= 0` as an always-true opaque condition)
+    {  // at most one precision mode
+        const int pbits = cfg->flags & (TT_R_EXACT_F32 | TT_R_SPLIT2 | TT_R_SPLIT3);
+        if (pbits & (pbits - 1)) return TT_ERR_BAD_ARG;
+    }
+#ifndef TT_TUNING
+    if (cfg->flags & (TT_R_WGRAD_F32 | TT_R_BWD_PAIR)) return TT_ERR_UNSUPPORTED;  // dev A/B kernels: tuning build only
+#endif
     if (!(cfg->skip_eps_tex >= 0.f) || !(cfg->skip_eps_geo >= 0.f)) return TT_ERR_BAD_ARG;
     return TT_OK;
 }
@@ -886,10 +905,13 @@ extern "C" int tt_render_fwd(const float* packed, const tt_mlp_weights* w, const
     if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
     p.queue = tt_queue_counters(s);
     if (!p.queue) return TT_ERR_DEVICE;
-    if (cfg->flags & TT_R_EXACT_F32)
-        hipLaunchKernelGGL((k_decode_rays<true, true, true>), dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
+    const int prec = tt_prec_of_r(cfg->flags);
+    if (prec == PREC_F32)
+        hipLaunchKernelGGL((k_decode_rays<true, true, PREC_F32>), dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
+    else if (prec == PREC_S3)
+        hipLaunchKernelGGL((k_decode_rays<true, true, PREC_S3>), dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
     else
-        hipLaunchKernelGGL((k_decode_rays<true, true, false>), dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
+        hipLaunchKernelGGL((k_decode_rays<true, true, PREC_S2>), dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
     st = tt_check_launch();
     if (st != TT_OK) return st;
     return tt_launch_march_fwd(rays_d, t_starts, t_ends, cfg, sdf, sdf_grad, features, opacity, depth, rgb_fg,
@@ -906,7 +928,7 @@ extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, cons
     if (st != TT_OK) return st;
     const bool need_n = (flags & TT_Q_NORMAL) != 0, need_t = (flags & TT_Q_TEX) != 0;
     if (!packed || !w || !rays_o || !rays_d || !t_starts || !t_ends || !sdf || (need_n && !sdf_grad) ||
-        (need_t && !features))
+        (need_t && !features) || !tt_qflags_ok(flags))
         return TT_ERR_BAD_ARG;
     if (!w->w1 || !w->w2 || !w->w3 || (need_t && (!w->v1 || !w->v2 || !w->v3))) return TT_ERR_BAD_ARG;
     int cus = tt_num_cus();
@@ -933,13 +955,16 @@ extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, cons
     if (p.n_items > (1LL << 30)) return TT_ERR_UNSUPPORTED;
     p.queue = tt_queue_counters(s);
     if (!p.queue) return TT_ERR_DEVICE;
-    const bool exact = ((flags & TT_Q_EXACT_F32) | (cfg->flags & TT_R_EXACT_F32)) != 0;
+    // precision: the query flags if they name one, else the render configuration's
+    const int prec = (flags & (TT_Q_EXACT_F32 | TT_Q_SPLIT2 | TT_Q_SPLIT3)) ? tt_prec_of_q(flags) : tt_prec_of_r(cfg->flags);
 #define LAUNCH_DR(N, T)                                                                  \
     do {                                                                                 \
-        if (exact)                                                                       \
-            hipLaunchKernelGGL((k_decode_rays<N, T, true>), grid, blk, 0, s, p);         \
+        if (prec == PREC_F32)                                                            \
+            hipLaunchKernelGGL((k_decode_rays<N, T, PREC_F32>), grid, blk, 0, s, p);     \
+        else if (prec == PREC_S3)                                                        \
+            hipLaunchKernelGGL((k_decode_rays<N, T, PREC_S3>), grid, blk, 0, s, p);      \
         else                                                                             \
-            hipLaunchKernelGGL((k_decode_rays<N, T, false>), grid, blk, 0, s, p);        \
+            hipLaunchKernelGGL((k_decode_rays<N, T, PREC_S2>), grid, blk, 0, s, p);      \
     } while (0)
     if (need_n && need_t)
         LAUNCH_DR(true, true);
@@ -962,7 +987,7 @@ extern "C" int tt_query_field(const float* packed, const tt_mlp_weights* w, cons
     if (!packed || !w || !points || !out_sdf || !out_deformation || n_batch <= 0 || n_points <= 0 || n_prompts <= 0 ||
         views_per_prompt <= 0)
         return TT_ERR_BAD_ARG;
-    if (n_batch != n_prompts * views_per_prompt || !(radius > 0.f)) return TT_ERR_BAD_ARG;
+    if (n_batch != n_prompts * views_per_prompt || !(radius > 0.f) || !tt_qflags_ok(flags)) return TT_ERR_BAD_ARG;
     if (plane_h != plane_w || plane_h <= 0) return TT_ERR_UNSUPPORTED;
     if (!w->w1 || !w->w2 || !w->w3 || !w->v1 || !w->v2 || !w->v3) return TT_ERR_BAD_ARG;
     QueryFieldParams p;
@@ -983,10 +1008,13 @@ extern "C" int tt_query_field(const float* packed, const tt_mlp_weights* w, cons
     long long n_tiles = ((n_points + TT_TILE - 1) / TT_TILE) * n_batch;
     long long blocks = (n_tiles + 3) / 4;
     if (blocks > 2LL * cus) blocks = 2LL * cus;
-    if (flags & TT_Q_EXACT_F32)
-        hipLaunchKernelGGL(k_query_field<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    const int prec = tt_prec_of_q(flags);
+    if (prec == PREC_F32)
+        hipLaunchKernelGGL(k_query_field<PREC_F32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else if (prec == PREC_S3)
+        hipLaunchKernelGGL(k_query_field<PREC_S3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(k_query_field<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_query_field<PREC_S2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return tt_check_launch();
 }
 
@@ -1033,9 +1061,12 @@ extern "C" int tt_render_eval(const float* packed, const tt_mlp_weights* w, cons
     hipStream_t s = (hipStream_t)stream;
     p.queue = tt_queue_counters(s);
     if (!p.queue) return TT_ERR_DEVICE;
-    if (cfg->flags & TT_R_EXACT_F32)
-        hipLaunchKernelGGL(k_render_eval<true>, dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
+    const int prec = tt_prec_of_r(cfg->flags);
+    if (prec == PREC_F32)
+        hipLaunchKernelGGL(k_render_eval<PREC_F32>, dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
+    else if (prec == PREC_S3)
+        hipLaunchKernelGGL(k_render_eval<PREC_S3>, dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
     else
-        hipLaunchKernelGGL(k_render_eval<false>, dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
+        hipLaunchKernelGGL(k_render_eval<PREC_S2>, dim3((unsigned)blocks), dim3(DECODE_THREADS), 0, s, p);
     return tt_check_launch();
 }

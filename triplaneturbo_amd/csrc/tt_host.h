@@ -9,6 +9,20 @@ int tt_num_cus();
 int tt_validate_cfg(const tt_render_cfg* cfg);
 bool tt_planes_too_large(long long n_prompts, int plane_h, int plane_w);  // packed planes >= 4 GB: unsupported
 
+// precision mode of a launch from its flag bits (tt_abi.h): 0 = two-piece split (fast), 1 = fp32 MFMA, 2 = three-piece
+// split (default) -- the PREC_* values of tt_mfma16.h.  More than one precision bit is rejected by tt_validate_cfg /
+// tt_validate_qflags.
+static inline int tt_prec_of_r(int flags) {
+    return (flags & TT_R_EXACT_F32) ? 1 : ((flags & TT_R_SPLIT2) ? 0 : 2);
+}
+static inline int tt_prec_of_q(int flags) {
+    return (flags & TT_Q_EXACT_F32) ? 1 : ((flags & TT_Q_SPLIT2) ? 0 : 2);
+}
+static inline bool tt_qflags_ok(int flags) {
+    const int pbits = flags & (TT_Q_EXACT_F32 | TT_Q_SPLIT2 | TT_Q_SPLIT3);
+    return (pbits & (pbits - 1)) == 0;
+}
+
 struct TileGeom;
 // fills the tile geometry / chunking for a render config; returns the number of work items.
 // default_order: order of an XCD's item queue, 0 = chunk-major, 1 = block-major (measured slightly faster in all

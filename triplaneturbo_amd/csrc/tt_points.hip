@@ -23,6 +23,12 @@
 #define PX_V2 (PX_V1 + IMG16_FLOATS(64, 96))
 #define PX_V3 (PX_V2 + IMG16_FLOATS(64, 64))
 #define PX_FLOATS (PX_V3 + 3 * 64) /* (the transposed products read the same images: mv16t) */
+// PREC_S3: images of the third terms, appended
+#define PXLO_W1 PX_FLOATS
+#define PXLO_W2 (PXLO_W1 + LO16_FLOATS(64, 32))
+#define PXLO_V1 (PXLO_W2 + LO16_FLOATS(64, 64))
+#define PXLO_V2 (PXLO_V1 + LO16_FLOATS(64, 96))
+#define PX3_FLOATS (PXLO_V2 + LO16_FLOATS(64, 64))
 
 struct PointsBwdXParams {
     const float* packed;
@@ -49,17 +55,17 @@ __device__ __forceinline__ float dot16_pair(const f32x4 (&t)[4], const float* v)
     return s + __shfl_xor(s, 32);
 }
 
-template <bool EXACT>
+template <int PREC>
 __global__ __launch_bounds__(256, 1) void k_points_bwd_x(PointsBwdXParams p) {
-    __shared__ __attribute__((aligned(16))) float L[PX_FLOATS];
+    __shared__ __attribute__((aligned(16))) float L[PREC == PREC_S3 ? PX3_FLOATS : PX_FLOATS];
     {
         const MlpPtrs w = p.w;
-        stage_weights<EXACT, 64, 32>(L + PX_W1, w.w1);
-        stage_weights<EXACT, 64, 64>(L + PX_W2, w.w2);
+        stage_weights<PREC, 64, 32>(L + PX_W1, L + PXLO_W1, w.w1);
+        stage_weights<PREC, 64, 64>(L + PX_W2, L + PXLO_W2, w.w2);
         lds_load_matrix(L + PX_W3, w.w3, 1, 64, 64);
         if (p.g_feat) {  // (block-uniform: the staging helpers synchronise)
-            stage_weights<EXACT, 64, 96>(L + PX_V1, w.v1);
-            stage_weights<EXACT, 64, 64>(L + PX_V2, w.v2);
+            stage_weights<PREC, 64, 96>(L + PX_V1, L + PXLO_V1, w.v1);
+            stage_weights<PREC, 64, 64>(L + PX_V2, L + PXLO_V2, w.v2);
             lds_load_matrix(L + PX_V3, w.v3, 3, 64, 64);
         }
     }
@@ -102,20 +108,20 @@ __global__ __launch_bounds__(256, 1) void k_points_bwd_x(PointsBwdXParams p) {
             const bool any = __any(gather_geo<false>(pbase, H, W, X, Y, Z, valid, 0.f, 0.f, hi, f, jx, jy, jz));
             if (any) {  // else f = 0: every mask false, q = 0
                 float h1[32], h2[32], a2[32], a1[32];
-                mvx<EXACT, 64, 32>(L + PX_W1, f, h1, i, hi);
+                mvx<PREC, 64, 32>(L + PX_W1, L + PXLO_W1, f, h1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) h1[r] = fmaxf(h1[r], 0.f);
-                mvx<EXACT, 64, 64>(L + PX_W2, h1, h2, i, hi);
+                mvx<PREC, 64, 64>(L + PX_W2, L + PXLO_W2, h1, h2, i, hi);
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     const f32x4 w3 = *reinterpret_cast<const f32x4*>(L + PX_W3 + 8 * g + 4 * hi);
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
                 }
-                mvtx<EXACT, 64, 64, 64>(L + PX_W2, 0, a2, a1, i, hi);
+                mvtx<PREC, 64, 64, 64>(L + PX_W2, L + PXLO_W2, 0, a2, a1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
-                mvtx<EXACT, 32, 64, 32>(L + PX_W1, 0, a1, q, i, hi);
+                mvtx<PREC, 32, 64, 32>(L + PX_W1, L + PXLO_W1, 0, a1, q, i, hi);
             }
         }
         if (need_tex) {
@@ -123,10 +129,10 @@ __global__ __launch_bounds__(256, 1) void k_points_bwd_x(PointsBwdXParams p) {
             const bool any = __any(gather_tex(pbase, H, W, X, Y, Z, valid, hi, e));
             if (any) {
                 float k1[32], k2[32], kb1[32];
-                mvx<EXACT, 64, 96>(L + PX_V1, e, k1, i, hi);
+                mvx<PREC, 64, 96>(L + PX_V1, L + PXLO_V1, e, k1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) k1[r] = fmaxf(k1[r], 0.f);
-                mvx<EXACT, 64, 64>(L + PX_V2, k1, k2, i, hi);
+                mvx<PREC, 64, 64>(L + PX_V2, L + PXLO_V2, k1, k2, i, hi);
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {  // k2bar = n2 . (V3^T gfeat)
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(L + PX_V3 + 0 * 64 + 8 * g + 4 * hi);
@@ -138,13 +144,13 @@ __global__ __launch_bounds__(256, 1) void k_points_bwd_x(PointsBwdXParams p) {
                         k2[4 * g + e2] = k2[4 * g + e2] > 0.f ? t : 0.f;
                     }
                 }
-                mvtx<EXACT, 64, 64, 64>(L + PX_V2, 0, k2, kb1, i, hi);
+                mvtx<PREC, 64, 64, 64>(L + PX_V2, L + PXLO_V2, 0, k2, kb1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) kb1[r] = k1[r] > 0.f ? kb1[r] : 0.f;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {  // ebar_p = (V1[:, 32p : 32p+32])^T k1bar
                     float ebp[16];
-                    mvtx<EXACT, 32, 64, 96>(L + PX_V1, 32 * pl, kb1, ebp, i, hi);
+                    mvtx<PREC, 32, 64, 96>(L + PX_V1, L + PXLO_V1, 32 * pl, kb1, ebp, i, hi);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) eb[16 * pl + r] = ebp[r];
                 }
@@ -237,9 +243,13 @@ extern "C" int tt_points_bwd_x(const float* packed, const tt_mlp_weights* w, con
     const long long n_tiles = ((n_points + TT_TILE - 1) / TT_TILE) * n_batch;
     long long blocks = (n_tiles + 3) / 4;
     if (blocks > cus) blocks = cus;
-    if (flags & TT_Q_EXACT_F32)
-        hipLaunchKernelGGL(k_points_bwd_x<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    if (!tt_qflags_ok(flags)) return TT_ERR_BAD_ARG;
+    const int prec = tt_prec_of_q(flags);
+    if (prec == PREC_F32)
+        hipLaunchKernelGGL(k_points_bwd_x<PREC_F32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else if (prec == PREC_S3)
+        hipLaunchKernelGGL(k_points_bwd_x<PREC_S3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(k_points_bwd_x<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_points_bwd_x<PREC_S2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return tt_check_launch();
 }

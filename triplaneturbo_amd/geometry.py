@@ -83,6 +83,7 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
         # TT_Q_EXACT_F32 for every per-point query of this module (forward and backward kernels): all matrix products
         # on the fp32-input MFMA instead of split-fp16.  Not a reference knob, so not in Config.
         self.exact_f32 = False
+        self.precision = None  # None / "split3" (default, fp32-grade) | "f32" | "split2" (fast): ops.RenderConfig.precision
 
     # ---- generator half: delegated (stock PyTorch-ROCm) ----
     def _gen(self):
@@ -132,7 +133,7 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
             sdf, grad, feat = ops.query_points_grad(space_cache, sw, fw, pts, views_per_prompt=B // P,
                                                     radius=self.cfg.radius,
                                                     sdf_bias_radius=float(self.cfg.sdf_bias_params),
-                                                    need_normal=output_normal, exact_f32=self.exact_f32)
+                                                    need_normal=output_normal, exact_f32=self.exact_f32, precision=self.precision)
         else:
             with torch.no_grad():
                 packed = ops.planes_pack(space_cache.detach())
@@ -140,7 +141,7 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
                                                    views_per_prompt=B // P, radius=self.cfg.radius,
                                                    sdf_bias_radius=float(self.cfg.sdf_bias_params),
                                                    need_normal=output_normal, need_features=True,
-                                                   exact_f32=self.exact_f32)
+                                                   exact_f32=self.exact_f32, precision=self.precision)
         bias = (pts.reshape(-1, 3) ** 2).sum(-1, keepdim=True).sqrt() - float(self.cfg.sdf_bias_params)
         out = {"sdf": sdf, "sdf_orig": sdf - bias, "features": feat}
         if output_normal:
@@ -155,7 +156,7 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
         pts = points.reshape(B, -1, 3).detach().float()
         sw, fw = self.mlp_weights()
         kw = dict(views_per_prompt=B // space_cache.shape[0], radius=self.cfg.radius,
-                  sdf_bias_radius=float(self.cfg.sdf_bias_params), exact_f32=self.exact_f32)
+                  sdf_bias_radius=float(self.cfg.sdf_bias_params), exact_f32=self.exact_f32, precision=self.precision)
         if self._wants_grad(space_cache, (sw,)):
             # (the feature head is evaluated too and gets no upstream gradient: its backward is skipped)
             sdf, _, _ = ops.query_points_grad(space_cache, sw, fw, pts, need_normal=False, **kw)
@@ -176,7 +177,7 @@ class StableDiffusionTriplaneDualAttention(BaseModule):
         sw, _ = self.mlp_weights()
         dw = self.deformation_network.weights()
         kw = dict(views_per_prompt=B // space_cache.shape[0], radius=self.cfg.radius,
-                  sdf_bias_radius=float(self.cfg.sdf_bias_params), exact_f32=self.exact_f32)
+                  sdf_bias_radius=float(self.cfg.sdf_bias_params), exact_f32=self.exact_f32, precision=self.precision)
         if self._wants_grad(space_cache, (sw, dw)):
             sdf, deform = ops.query_field_grad(space_cache, sw, dw, pts, **kw)
         else:

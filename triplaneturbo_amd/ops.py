@@ -108,9 +108,17 @@ class RenderConfig:
     tile_sb: int = 0  # consecutive samples of a ray per kernel tile (performance knob): 0 = default (2), 8 importance
     grad_copies: int = 1  # privatised copies of the plane-gradient buffer in the backward (performance knob)
     tile_chunk: int = 0  # samples of a ray block per work item (performance knob); 0 = automatic
-    exact_f32: bool = False  # TT_R_EXACT_F32: all matrix products on the fp32-input MFMA (A/B reference, ~1.6x slower)
-    wgrad_f32: bool = False  # TT_R_WGRAD_F32: weight-gradient outer products on the fp32 MFMA (A/B of the fp16 ones)
-    bwd_pair: bool = False  # TT_R_BWD_PAIR: the wave-pair texture backward kernel (A/B switch; default: one wave per tile)
+    # precision of the MLP products (include/tt_abi.h): None / "split3" = fp32-grade three-piece products on the fp16 pipe
+    # (default: the reference's precision, networks.py:91-97), "f32" = the fp32-input MFMA (A/B reference), "split2" /
+    # "fast" = the two-piece fast mode of rounds 2-4 (~2^-21.5 per product).  exact_f32=True is the old spelling of "f32".
+    precision: Optional[str] = None
+    exact_f32: bool = False
+    wgrad_f32: bool = False  # TT_R_WGRAD_F32: tuning build only (the product library rejects it)
+    bwd_pair: bool = False  # TT_R_BWD_PAIR: tuning build only (the product library rejects it)
+
+    @property
+    def prec(self) -> str:
+        return _lib.resolve_precision(self.precision, self.exact_f32)
     # OPT-IN approximation of the backward (0 = exact): skip 32-sample tiles whose upstream gradients are all below the
     # threshold (tt_render_cfg.skip_eps_tex / skip_eps_geo in include/tt_abi.h; error measured in tests/test_gpu_skip.py)
     skip_eps_tex: float = 0.0
@@ -171,7 +179,8 @@ def pack_planes(space_cache: Tensor) -> Tensor:
 
 def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Sequence[Tensor]], points: Tensor,
                  views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5,
-                 need_normal: bool = True, need_features: bool = True, exact_f32: bool = False):
+                 need_normal: bool = True, need_features: bool = True, exact_f32: bool = False,
+                 precision: Optional[str] = None):
     """Per-point decode (no grad). points (B,N,3) -> sdf (B*N,1), sdf_grad (B*N,3)|None, features (B*N,3)|None."""
     packed = _chk(packed, "packed")
     points = _chk(points, "points")
@@ -182,8 +191,8 @@ def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Seque
     sdf = torch.empty((B * N, 1), device=dev, dtype=torch.float32)
     grad = torch.empty((B * N, 3), device=dev, dtype=torch.float32) if need_normal else None
     feat = torch.empty((B * N, 3), device=dev, dtype=torch.float32) if need_features else None
-    flags = (_lib.TT_Q_NORMAL if need_normal else 0) | (_lib.TT_Q_TEX if need_features else 0) | (
-        _lib.TT_Q_EXACT_F32 if exact_f32 else 0)
+    flags = (_lib.TT_Q_NORMAL if need_normal else 0) | (_lib.TT_Q_TEX if need_features else 0) | _lib.q_flag(
+        _lib.resolve_precision(precision, exact_f32))
     st = _lib.load().tt_query_points(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, views_per_prompt, H, W,
                                      radius, sdf_bias_radius, flags, _ptr(sdf), _ptr(grad), _ptr(feat), _stream())
     _lib.check(st, "tt_query_points")
@@ -191,7 +200,8 @@ def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Seque
 
 
 def query_field(packed: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tensor], points: Tensor,
-                views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5, exact_f32: bool = False):
+                views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5, exact_f32: bool = False,
+                precision: Optional[str] = None):
     """sdf (B*N,1) and deformation (B*N,3) from the geometry planes (forward_field)."""
     packed = _chk(packed, "packed")
     points = _chk(points, "points")
@@ -204,7 +214,7 @@ def query_field(packed: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tens
     sdf = torch.empty((B * N, 1), device=points.device, dtype=torch.float32)
     deform = torch.empty((B * N, 3), device=points.device, dtype=torch.float32)
     st = _lib.load().tt_query_field(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, views_per_prompt, H, W,
-                                    radius, sdf_bias_radius, _lib.TT_Q_EXACT_F32 if exact_f32 else 0, _ptr(sdf),
+                                    radius, sdf_bias_radius, _lib.q_flag(_lib.resolve_precision(precision, exact_f32)), _ptr(sdf),
                                     _ptr(deform), _stream())
     _lib.check(st, "tt_query_field")
     return sdf, deform
@@ -220,14 +230,14 @@ class _QueryPointsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, space_cache, w1, w2, w3, v1, v2, v3, points, views_per_prompt, radius, sdf_bias_radius,
-                need_normal, exact_f32):
+                need_normal, prec):
         ctx.set_materialize_grads(False)
         packed = planes_pack(space_cache)
         sdf, grad, feat = query_points(packed, (w1, w2, w3), (v1, v2, v3), points, views_per_prompt, radius,
                                        sdf_bias_radius, need_normal=need_normal, need_features=True,
-                                       exact_f32=exact_f32)
+                                       precision=prec)
         ctx.save_for_backward(packed, w1, w2, w3, v1, v2, v3, points)
-        ctx.meta = (views_per_prompt, radius, sdf_bias_radius, _lib.TT_Q_EXACT_F32 if exact_f32 else 0)
+        ctx.meta = (views_per_prompt, radius, sdf_bias_radius, _lib.q_flag(prec))
         if grad is None:
             grad = sdf.new_zeros((sdf.shape[0], 3))
             ctx.mark_non_differentiable(grad)
@@ -272,13 +282,13 @@ class _QueryPointsFn(torch.autograd.Function):
 
 def query_points_grad(space_cache: Tensor, sdf_w: Sequence[Tensor], feat_w: Sequence[Tensor], points: Tensor,
                       views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5,
-                      need_normal: bool = True, exact_f32: bool = False):
+                      need_normal: bool = True, exact_f32: bool = False, precision: Optional[str] = None):
     """Differentiable per-point decode: sdf (B*N,1), sdf_grad (B*N,3) (zeros, non-differentiable, when
     need_normal is False), features (B*N,3); autograd-connected to space_cache, the six MLP matrices and -- when
-    `points` requires grad -- the points.  exact_f32: TT_Q_EXACT_F32 in the forward and every backward kernel."""
+    `points` requires grad -- the points.  precision / exact_f32: the mode of the forward and every backward kernel."""
     return _QueryPointsFn.apply(space_cache, sdf_w[0], sdf_w[1], sdf_w[2], feat_w[0], feat_w[1], feat_w[2],
                                 _chk(points, "points"), int(views_per_prompt), float(radius), float(sdf_bias_radius),
-                                bool(need_normal), bool(exact_f32))
+                                bool(need_normal), _lib.resolve_precision(precision, bool(exact_f32)))
 
 
 class _QueryFieldFn(torch.autograd.Function):
@@ -289,13 +299,13 @@ class _QueryFieldFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, space_cache, w1, w2, w3, d1, d2, d3, points, views_per_prompt, radius, sdf_bias_radius,
-                exact_f32):
+                prec):
         ctx.set_materialize_grads(False)
         packed = planes_pack(space_cache)
         sdf, deform = query_field(packed, (w1, w2, w3), (d1, d2, d3), points, views_per_prompt, radius,
-                                  sdf_bias_radius, exact_f32=exact_f32)
+                                  sdf_bias_radius, precision=prec)
         ctx.save_for_backward(packed, w1, w2, w3, d1, d2, d3, points)
-        ctx.meta = (views_per_prompt, radius, sdf_bias_radius, _lib.TT_Q_EXACT_F32 if exact_f32 else 0)
+        ctx.meta = (views_per_prompt, radius, sdf_bias_radius, _lib.q_flag(prec))
         return sdf, deform
 
     @staticmethod
@@ -331,12 +341,27 @@ class _QueryFieldFn(torch.autograd.Function):
 
 def query_field_grad(space_cache: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tensor], points: Tensor,
                      views_per_prompt: int = 1, radius: float = 1.0, sdf_bias_radius: float = 0.5,
-                     exact_f32: bool = False):
+                     exact_f32: bool = False, precision: Optional[str] = None):
     """Differentiable field query: sdf (B*N,1), deformation (B*N,3); autograd-connected to space_cache, the sdf net
     and the deformation net."""
     return _QueryFieldFn.apply(space_cache, sdf_w[0], sdf_w[1], sdf_w[2], deform_w[0], deform_w[1], deform_w[2],
                                _chk(points, "points"), int(views_per_prompt), float(radius), float(sdf_bias_radius),
-                               bool(exact_f32))
+                               _lib.resolve_precision(precision, bool(exact_f32)))
+
+
+def _inv_std_args(rc: RenderConfig):
+    """(host inv_std clamped like LearnedVariance.forward, renderer :34-35; device pointer of rc.inv_std_t or None).  ONE
+    place validates the device scalar -- CUDA, fp32, current device, one element -- for every wrapper that hands it to a
+    kernel (a CPU / fp64 / other-GPU tensor would be a wild pointer there)."""
+    inv_std = min(max(float(rc.inv_std), 1.0e-6), 1.0e6)
+    if rc.inv_std_t is None:
+        return inv_std, None
+    t = _chk(rc.inv_std_t, "inv_std_t")
+    if t.numel() != 1:
+        raise ValueError("inv_std_t must hold one float")
+    if t.data_ptr() != rc.inv_std_t.data_ptr():
+        raise ValueError("inv_std_t must be a contiguous float32 CUDA tensor (the kernels read it in place)")
+    return inv_std, t.data_ptr()  # (the tensor is kept alive by `rc`, which the callers hold across the launch)
 
 
 def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, rc: RenderConfig,
@@ -345,13 +370,7 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
     n_views = n_rays // rays_per_view
     if n_views * rays_per_view != n_rays or n_views % P != 0:
         raise ValueError(f"n_rays={n_rays} is not views*rays_per_view with views a multiple of P={P}")
-    inv_std = min(max(float(rc.inv_std), 1.0e-6), 1.0e6)  # LearnedVariance.forward clamp, renderer :34-35
-    inv_std_dev = None
-    if rc.inv_std_t is not None:
-        t = _chk(rc.inv_std_t, "inv_std_t")
-        if t.numel() != 1:
-            raise ValueError("inv_std_t must hold one float")
-        inv_std_dev = t.data_ptr()  # (the tensor is kept alive by `rc`, which the callers hold across the launch)
+    inv_std, inv_std_dev = _inv_std_args(rc)
     stats = None
     if rc.stats is not None:
         if rc.stats.dtype != torch.int64 or not rc.stats.is_cuda or tuple(rc.stats.shape) != (3, 4):
@@ -359,7 +378,7 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
         stats = rc.stats.data_ptr() + 32 * stats_row
     return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
                           inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
-                          (_lib.TT_R_PER_SAMPLE if per_sample else 0) | (_lib.TT_R_EXACT_F32 if rc.exact_f32 else 0) |
+                          (_lib.TT_R_PER_SAMPLE if per_sample else 0) | _lib.r_flag(rc.prec) |
                           (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0) | (_lib.TT_R_BWD_PAIR if rc.bwd_pair else 0),
                           image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0, int(rc.tile_sb),
                           max(1, int(rc.grad_copies)), max(0, int(rc.tile_chunk)), max(0.0, float(rc.skip_eps_tex)),
@@ -501,11 +520,11 @@ def march_forward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, sdf: Ten
     n_rays, S = t_starts.shape
     if sdf.numel() != n_rays * S or sdf_grad.numel() != 3 * n_rays * S or features.numel() != 3 * n_rays * S:
         raise ValueError("per-sample tensors do not match (n_rays, S)")
+    inv_std, inv_std_dev = _inv_std_args(rc)
     cfg = _lib.RenderCfg(n_prompts=1, views_per_prompt=1, plane_h=1, plane_w=1, rays_per_view=n_rays, n_samples=S,
-                         n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=rc.inv_std,
+                         n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=inv_std,
                          cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink, flags=0, image_w=0,
-                         tile_sb=0, grad_copies=1, tile_chunk=0,
-                         inv_std_dev=None if rc.inv_std_t is None else rc.inv_std_t.data_ptr())
+                         tile_sb=0, grad_copies=1, tile_chunk=0, inv_std_dev=inv_std_dev)
     f32 = dict(device=rays_d.device, dtype=torch.float32)
     if out is None:
         out = {"opacity": torch.empty((n_rays, 1), **f32), "depth": torch.empty((n_rays, 1), **f32),
@@ -530,11 +549,11 @@ def march_backward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, fwd: di
     the dict march_forward_raw / render_forward_raw returned (opacity, depth, trans).  g_inv_std_rays (n_rays), if
     given, receives d loss / d inv_std per ray."""
     n_rays, S = t_starts.shape
+    inv_std, inv_std_dev = _inv_std_args(rc)
     cfg = _lib.RenderCfg(n_prompts=1, views_per_prompt=1, plane_h=1, plane_w=1, rays_per_view=n_rays, n_samples=S,
-                         n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=rc.inv_std,
+                         n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=inv_std,
                          cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink, flags=0, image_w=0,
-                         tile_sb=0, grad_copies=1, tile_chunk=0,
-                         inv_std_dev=None if rc.inv_std_t is None else rc.inv_std_t.data_ptr())
+                         tile_sb=0, grad_copies=1, tile_chunk=0, inv_std_dev=inv_std_dev)
     if out is None:
         out = torch.empty((n_rays * S, 4), device=rays_d.device, dtype=torch.float32)
     c = lambda t: None if t is None else t.contiguous()
