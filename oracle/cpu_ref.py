@@ -53,28 +53,70 @@ Tensor = torch.Tensor
 # A SECOND fp32 evaluation order (round 5): the same math, different rounding
 # --------------------------------------------------------------------------
 # fp32 arithmetic does not define ONE answer for this renderer: NeuS alpha is a ratio of nearly equal sigmoids scaled by
-# inv_std = 100, so in ill-conditioned scenes two correct fp32 evaluations that merely add in a different order differ by
-# 1e-4 ... 1e-2 in the gradients.  To MEASURE that sensitivity per case (instead of inferring it from the distance to
-# fp64), every sum in the decode can be evaluated in a second, documented order:
+# inv_std = 100, and comp_normal normalises an accumulated normal that can nearly cancel, so in ill-conditioned scenes two
+# correct fp32 evaluations that merely add in a different order -- or use a different, equally valid fp32 sigmoid -- differ
+# by 1e-4 ... 1e-2 in the gradients.  To MEASURE that sensitivity per case (instead of inferring it from the distance to
+# fp64), the decode and the march can be evaluated in two more documented ways:
+#   alt_order(1)
 #   * nn.Linear (vanilla_mlp): the K input channels in REVERSED order, accumulated in blocks of 8 (block partial sums
 #     first, blocks added last-to-first) -- the reference / default order is torch's GEMM over k = 0 .. K-1;
 #   * bilinear blend (grid_sample_gather): corners se, sw, ne, nw instead of nw, ne, sw, se;
 #   * v1 plane sum (sample_from_planes): planes 2, 1, 0 instead of 0, 1, 2;
-#   * accumulate_along_rays (render): samples far-to-near instead of near-to-far.
-# Same operations, same operands, same dtype: |fp32 - fp32'| is the order sensitivity of the fp32 oracle itself, and
-# tests/parity.py asks of the HIP path  |hip - fp32| <= max(1e-4, 1.5 |fp32 - fp32'|).
-_ALT_ORDER = False
+#   * accumulate_along_rays (render): samples far-to-near instead of near-to-far;
+#   * the logistic function (get_alpha, proposal_density, sigmoid_mipnerf): evaluated in fp64 and rounded to fp32 -- a
+#     CORRECTLY ROUNDED fp32 sigmoid -- instead of torch's fp32 kernel (a vectorised exp with ~1 ulp error): the difference
+#     between two valid fp32 implementations of the same function, and the one that matters most, because NeuS alpha
+#     subtracts two nearly equal logistics.
+#   * F.normalize (per-sample normal, comp_normal): x * rsqrt(max(|x|^2, eps^2)) with |x|^2 summed z-first;
+#   * the sphere bias |x| with the squares summed z-first.
+#   alt_order(2)
+#   * F.normalize: x * (1 / max(|x|, eps)) -- reciprocal-multiply instead of the division;
+#   * nn.Linear: channels in natural order, blocks of 16, block partial sums added first-to-last;
+#   * corners ne, nw, se, sw;  planes (0 + 2) + 1;  samples accumulated in two halves (near half + far half);
+#   * the logistic function in its two-branch fp32 form: 1 / (1 + exp(-x)) for x >= 0, exp(x) / (1 + exp(x)) for x < 0.
+# Same operations, same operands, same dtype: the pairwise distances of the three fp32 evaluations are the order /
+# implementation sensitivity of the fp32 math itself on that scene, and tests/parity.py asks of the HIP path
+#     |hip - fp32| <= max(1e-4, 1.5 x the largest of those distances).
+_ALT_ORDER = 0
 
 
 @contextlib.contextmanager
-def alt_order(on: bool = True):
-    """Evaluate every sum of the decode / march in the second operation order described above."""
+def alt_order(level=1):
+    """Evaluate every sum / logistic of the decode and the march in alternative way `level` (0 / False = the default order,
+    True = 1)."""
     global _ALT_ORDER
-    prev, _ALT_ORDER = _ALT_ORDER, bool(on)
+    prev, _ALT_ORDER = _ALT_ORDER, int(level)
     try:
         yield
     finally:
         _ALT_ORDER = prev
+
+
+def _sigmoid(x: Tensor) -> Tensor:
+    """torch.sigmoid(x) -- or, under alt_order() on fp32 input, another valid fp32 logistic (see above)."""
+    if _ALT_ORDER == 1 and x.dtype == torch.float32:
+        return torch.sigmoid(x.double()).float()
+    if _ALT_ORDER == 2:
+        e = torch.exp(-x.abs())
+        return torch.where(x >= 0, 1.0 / (1.0 + e), e / (1.0 + e))
+    return torch.sigmoid(x)
+
+
+def _normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
+    """F.normalize(x, dim=-1) -- or, under alt_order(), one of two other valid fp32 forms (see above)."""
+    if _ALT_ORDER == 1:
+        n2 = (x[..., 2:3] ** 2 + x[..., 1:2] ** 2) + x[..., 0:1] ** 2
+        return x * torch.rsqrt(n2.clamp_min(eps * eps))
+    if _ALT_ORDER == 2:
+        return x * (1.0 / torch.linalg.norm(x, dim=-1, keepdim=True).clamp_min(eps))
+    return F.normalize(x, dim=-1, eps=eps)
+
+
+def _norm3(x: Tensor) -> Tensor:
+    """|x| of (..., 3) with keepdim, as (x ** 2).sum(-1).sqrt() -- under alt_order(1) with the squares summed z-first."""
+    if _ALT_ORDER == 1:
+        return ((x[..., 2:3] ** 2 + x[..., 1:2] ** 2) + x[..., 0:1] ** 2).sqrt()
+    return (x ** 2).sum(dim=-1, keepdim=True).sqrt()
 
 
 def _linear(x: Tensor, w: Tensor) -> Tensor:
@@ -83,10 +125,15 @@ def _linear(x: Tensor, w: Tensor) -> Tensor:
         return F.linear(x, w)
     K = w.shape[1]
     out = None
-    for k1 in range(K, 0, -8):  # blocks last-to-first
-        k0 = max(k1 - 8, 0)
-        part = F.linear(x[..., k0:k1].flip(-1), w[:, k0:k1].flip(-1))
-        out = part if out is None else out + part
+    if _ALT_ORDER == 1:
+        for k1 in range(K, 0, -8):  # reversed channels, blocks of 8 last-to-first
+            k0 = max(k1 - 8, 0)
+            part = F.linear(x[..., k0:k1].flip(-1), w[:, k0:k1].flip(-1))
+            out = part if out is None else out + part
+    else:
+        for k0 in range(0, K, 16):  # natural order, blocks of 16 first-to-last
+            part = F.linear(x[..., k0:k0 + 16], w[:, k0:k0 + 16])
+            out = part if out is None else out + part
     return out
 
 
@@ -173,7 +220,11 @@ def grid_sample_gather(inp: Tensor, grid: Tensor, padding_mode: str = "zeros", a
     flat = inp.permute(0, 2, 3, 1).reshape(N, H * W, C)
     out = None
     corners = bilinear_corners(grid, H, W, padding_mode, align_corners)
-    for cy, cx, w, inb in (corners[::-1] if _ALT_ORDER else corners):
+    if _ALT_ORDER == 1:
+        corners = corners[::-1]
+    elif _ALT_ORDER == 2:
+        corners = [corners[1], corners[0], corners[3], corners[2]]
+    for cy, cx, w, inb in corners:
         idx = (cy.clamp(0, H - 1) * W + cx.clamp(0, W - 1)).long()  # (N, M)
         val = torch.gather(flat, 1, idx[..., None].expand(-1, -1, C))
         val = val * inb[..., None].to(inp.dtype)
@@ -195,8 +246,10 @@ def sample_from_planes(plane_features: Tensor, coordinates: Tensor, interpolate_
     feats = grid_sample_gather(plane_features.reshape(N * n_planes, C, H, W), proj)
     feats = feats.reshape(N, n_planes, M, C)
     if interpolate_feat in (None, "v1"):
-        if _ALT_ORDER:
+        if _ALT_ORDER == 1:
             return (feats[:, 2] + feats[:, 1]) + feats[:, 0]
+        if _ALT_ORDER == 2:
+            return (feats[:, 0] + feats[:, 2]) + feats[:, 1]
         return feats.sum(dim=1)
     elif interpolate_feat == "v2":
         return feats.permute(0, 2, 1, 3).reshape(N, M, n_planes * C)
@@ -217,7 +270,7 @@ def vanilla_mlp(x: Tensor, weights: Sequence[Tensor]) -> Tensor:
 
 def sigmoid_mipnerf(x: Tensor) -> Tensor:
     """threestudio/utils/ops.py:118-119"""
-    return torch.sigmoid(x) * (1 + 2 * 0.001) - 0.001
+    return _sigmoid(x) * (1 + 2 * 0.001) - 0.001
 
 
 def scale_tensor(dat: Tensor, inp_scale, tgt_scale) -> Tensor:
@@ -249,7 +302,7 @@ def geometry_forward(points: Tensor, space_cache: Tensor, sdf_weights: Sequence[
         enc_geo = sample_from_planes(rot[:, 0:3], pts, "v1")
         enc_tex = sample_from_planes(rot[:, 3:6], pts, "v2")
         sdf_orig = vanilla_mlp(enc_geo, sdf_weights).view(B, N, 1)
-        sdf_bias = (points_unscaled ** 2).sum(dim=-1, keepdim=True).sqrt() - sdf_bias_radius
+        sdf_bias = _norm3(points_unscaled) - sdf_bias_radius
         sdf = sdf_orig + sdf_bias
         features = vanilla_mlp(enc_tex, feat_weights).view(B, N, -1)
         out = {
@@ -262,7 +315,7 @@ def geometry_forward(points: Tensor, space_cache: Tensor, sdf_weights: Sequence[
         if output_normal:
             sdf_grad = torch.autograd.grad(sdf, points_unscaled, grad_outputs=torch.ones_like(sdf),
                                            create_graph=create_graph)[0]
-            normal = F.normalize(sdf_grad, dim=-1)
+            normal = _normalize(sdf_grad)
             if not create_graph:
                 sdf_grad, normal = sdf_grad.detach(), normal.detach()
             out.update(normal=normal.reshape(B * N, 3), shading_normal=normal.reshape(B * N, 3),
@@ -281,8 +334,8 @@ def get_alpha(sdf: Tensor, normal: Tensor, dirs: Tensor, dists: Tensor, inv_std:
                  + F.relu(-true_cos) * cos_anneal_ratio)
     estimated_next_sdf = sdf + iter_cos * dists * 0.5
     estimated_prev_sdf = sdf - iter_cos * dists * 0.5
-    prev_cdf = torch.sigmoid(estimated_prev_sdf * inv_std)
-    next_cdf = torch.sigmoid(estimated_next_sdf * inv_std)
+    prev_cdf = _sigmoid(estimated_prev_sdf * inv_std)
+    next_cdf = _sigmoid(estimated_next_sdf * inv_std)
     p = prev_cdf - next_cdf
     c = prev_cdf
     return ((p + 1e-5) / (c + 1e-5)).clip(0.0, 1.0)
@@ -292,8 +345,8 @@ def proposal_density(sdf: Tensor, inv_std: float, render_step_size: float) -> Te
     """generative_space_sdf_volume_renderer.py:288-297 (fixed-step NeuS density of the proposal pass)."""
     estimated_next_sdf = sdf - render_step_size * 0.5
     estimated_prev_sdf = sdf + render_step_size * 0.5
-    prev_cdf = torch.sigmoid(estimated_prev_sdf * inv_std)
-    next_cdf = torch.sigmoid(estimated_next_sdf * inv_std)
+    prev_cdf = _sigmoid(estimated_prev_sdf * inv_std)
+    next_cdf = _sigmoid(estimated_next_sdf * inv_std)
     p = prev_cdf - next_cdf
     c = prev_cdf
     alpha = ((p + 1e-5) / (c + 1e-5)).clip(0.0, 1.0)
@@ -356,11 +409,13 @@ def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Seq
         # nerfacc.accumulate_along_rays (call sites :414-431, :467-472)
         src = weights if values is None else weights * values
         src = src.reshape(n_rays, S, -1)
-        if _ALT_ORDER:  # far-to-near, one sample at a time
+        if _ALT_ORDER == 1:  # far-to-near, one sample at a time
             acc = src[:, S - 1]
             for k in range(S - 2, -1, -1):
                 acc = acc + src[:, k]
             return acc
+        if _ALT_ORDER == 2 and S > 1:  # near half + far half
+            return src[:, :S // 2].sum(dim=1) + src[:, S // 2:].sum(dim=1)
         return src.sum(dim=1)
 
     opacity = accumulate(None)
@@ -393,7 +448,7 @@ def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Seq
     # :466-505 (normal_direction == "camera")
     normal_acc = accumulate(geo["normal"])
     out["normal_acc"] = normal_acc  # un-normalised sum_i w_i n_i (what tt_render_fwd returns)
-    comp_normal = F.normalize(normal_acc, dim=-1)
+    comp_normal = _normalize(normal_acc)
     out["comp_normal"] = comp_normal.view(B, Hh, Ww, 3)
     bg_normal = 0.5 * torch.ones_like(comp_normal)
     bg_normal[:, 2] = 1.0

@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu via gpurun)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """The CPU oracle works on small gather / scatter-heavy tensors: torch's intra-op threading over every core of a
+    256-core GPU host is many times SLOWER there than a handful of threads (bench.py: cpu_baseline measures it).  Cap it;
+    TT_ORACLE_THREADS overrides."""
+    import torch
+    n = int(os.environ.get("TT_ORACLE_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(n)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

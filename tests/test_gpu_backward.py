@@ -60,6 +60,7 @@ def _rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
+_ORACLE_CACHE = {}
 NAMES = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]
 
 
@@ -127,10 +128,16 @@ def test_backward_matches_oracle(mods, P, R, n_view, Hh, Ww, S, seed, precision)
     proj = {n: torch.randn(P * n_view, Hh, Ww, c, generator=g) for n, c in KEYS}
     rck = dict(inv_std=100.0, rgb_grad_shrink=0.7, cos_anneal_ratio=1.0)
     _, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, dict(rck, precision=precision))
-    _, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
-    _, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+    key = (P, R, n_view, Hh, Ww, S, seed)
+    if key not in _ORACLE_CACHE:  # the same four oracle evaluations serve the three precision modes
+        a = (cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
+        _ORACLE_CACHE[key] = (_oracle_grads(torch.float32, *a)[1:], _oracle_grads(torch.float64, *a)[1:],
+                              [_oracle_grads(torch.float32, *a, alt_order=lv)[2] for lv in (1, 2)])
+    (l32, g32), (l64, g64), g32a = _ORACLE_CACHE[key]
     assert abs(l_hip - l64) <= max(4 * abs(l32 - l64), 1e-5 * abs(l64))
-    print(_check(g_hip, g32, g64))
+    # g32_alt: the fp32 oracle's own order / implementation sensitivity, measured (tests/parity.py: ORDER_K) -- case 4 is
+    # ill-conditioned at the 6e-4 level (comp_normal normalises a nearly cancelling accumulated normal on one ray)
+    print(_check(g_hip, g32, g64, g32_alt=g32a))
 
 
 @pytest.mark.parametrize("chunk,blocked,sb", [(1, True, 1), (7, True, 1), (64, True, 1), (5, False, 1), (9, True, 2),

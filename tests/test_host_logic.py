@@ -316,3 +316,20 @@ def test_no_kernel_selects_on_a_scalar_alu_combination_of_fresh_compare_masks(tm
                    cwd=str(tmp_path))
     flagged = L.lint(str(probe), window=4, fresh=16)
     assert any("k_textbook_corners" in k for k in flagged), flagged
+
+
+def test_load_never_binds_a_stale_library_silently(monkeypatch):
+    """_lib.load() compares the source hash embedded in libtt_hip.so with the hash of the checkout and rebuilds (or raises
+    when there is no hipcc) on a mismatch -- a plugin user who only imports the package must not get a library built from
+    other sources."""
+    _lib.build()
+    calls = []
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "source_hash", lambda *a, **k: "0" * 64)
+    monkeypatch.setattr(_lib, "build", lambda *a, **k: calls.append(1) or _lib.LIB_PATH)
+    _lib.load()
+    assert calls == [1]
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
+    with pytest.raises(RuntimeError, match="different sources"):
+        _lib.load()

@@ -20,6 +20,7 @@ INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libtt_hip.so")
 # dev-only variant built with -DTT_TUNING: honours the TT_DEBUG_FLAGS / TT_SB / TT_CHUNK / TT_UNIT / TT_ORDER
 # environment variables (profiling ablations and tuning sweeps, tools/).  The product library above never calls getenv.
+_DEFAULT_LIB_PATH = LIB_PATH
 TUNING_LIB_PATH = os.path.join(_HERE, "libtt_hip_tuning.so")
 SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_backward_tex.hip", "tt_backward_tex2.hip", "tt_points.hip", "tt_composite.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
 # per-translation-unit flags: the texture backward is faster under hipcc's max-ILP scheduling strategy (3.11 -> 3.02 ms;
@@ -266,6 +267,14 @@ def load() -> ctypes.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (hipcc --offload-arch=gfx950). triplaneturbo_amd has no CPU/PyTorch fallback.")
+    if LIB_PATH == _DEFAULT_LIB_PATH and embedded_hash(LIB_PATH) != source_hash():
+        # a library built from OTHER sources (an edited checkout, a stale copy): never bind it silently -- rebuild in-tree,
+        # or say so when there is no compiler (dev variants bound by use_variant / use_tuning_build carry their own hash)
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        if not os.path.exists(hipcc):
+            raise RuntimeError(f"{LIB_PATH} was built from different sources than this checkout (embedded hash "
+                               f"{embedded_hash(LIB_PATH)}, tree {source_hash()}) and {hipcc} is not there to rebuild it")
+        build()
     lib = ctypes.CDLL(LIB_PATH)
     missing = [s for s in SYMBOLS if not hasattr(lib, s)]
     if missing:

@@ -9,11 +9,33 @@ struct AlphaTerms {
     float prev_sdf, next_sdf;  // the estimated sdf at the ends of the interval (d/d inv_std needs them)
 };
 
-__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }  // 1 ulp
-// logistic function on the hardware exp2 / rcp (2 + 2 instructions instead of ~25 for 1 / (1 + expf(-x)) with the
-// IEEE division): relative error ~|x| 2^-24 from the rounded x log2(e), i.e. <= 1e-6 wherever the result is not
-// saturated; overflow of exp2 for x < -88 gives rcp(inf) = 0 like the reference
-__device__ __forceinline__ float sigmoid_(float x) { return rcp_(1.f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
+// 1 / x for finite, non-zero x: the hardware reciprocal (1 ulp) + one Newton step = within ~0.5 ulp of the IEEE quotient
+// (round 5: with fp32-grade MLP products the march's own approximations became the largest difference to the reference's
+// arithmetic -- NeuS alpha is a DIFFERENCE of nearly equal logistics, so every ulp of them is amplified; tools/fuzz_seeds.py,
+// seeds 5 / 198 / 229 / 391: all three precision modes equally far from the fp32 oracle).  The march kernels are HBM-bound:
+// the extra FMAs are free there.
+__device__ __forceinline__ float rcp_(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+#ifdef TT_FAST_RCP  // (dev A/B: rounds 1-4)
+    return r;
+#else
+    return fmaf(fmaf(-x, r, 1.f), r, r);
+#endif
+}
+// logistic function 1 / (1 + exp(-x)) on the hardware exp2 + reciprocal, to ~2 ulp: the argument t = -x log2(e) is carried
+// as a pair (t_hi = rn(x c_hi), t_lo = the rounding error of that product + x c_lo: ~2^-48 |t|), exp2(t_hi) corrected by
+// (1 + ln2 t_lo) -- rounds 1-4 used exp2(rn(x c)) alone, whose relative error grows as |x| 2^-24 (1e-6 at |x| = 20).
+// t is clamped at 126 so that 1 + exp2(t) stays finite (x < -87: the result is ~1e-38 instead of the reference's 0 / denormal).
+__device__ __forceinline__ float sigmoid_(float x) {
+#ifdef TT_FAST_LOGISTIC  // (dev A/B: rounds 1-4)
+    return rcp_(1.f + __builtin_amdgcn_exp2f(x * -1.44269504f));
+#endif
+    const float c_hi = -1.44269504f, c_lo = -1.92596303e-8f;  // -log2(e) = c_hi + c_lo
+    const float t_hi = fminf(x * c_hi, 126.f);
+    const float t_lo = fmaf(x, c_hi, -(x * c_hi)) + x * c_lo;
+    const float e = __builtin_amdgcn_exp2f(t_hi);
+    return rcp_(1.f + fmaf(e, t_lo * 0.693147181f, e));
+}
 
 // inv_std of the launch: a device scalar when the caller gave one (tt_render_cfg.inv_std_dev: trainable variance, no host
 // read-back), with LearnedVariance.forward's clamp (renderer :34-35); else the host value of the config
@@ -37,7 +59,7 @@ __device__ __forceinline__ AlphaTerms neus_alpha_terms(float sdf, float cosv, fl
     a.rat = ((a.sA - a.sB) + 1e-5f) * rcp_(a.den);
     a.alpha = fminf(fmaxf(a.rat, 0.f), 1.f);
     // 1 inside the clip, 0 outside -- a FACTOR made of single compares, not a combined lane mask (tt_device.h, corners_setup)
-    a.pass = (a.rat >= 0.f ? 1.f : 0.f) * (a.rat <= 1.f ? 1.f : 0.f);
+    a.pass = tt_opaque(a.rat >= 0.f ? 1.f : 0.f) * (a.rat <= 1.f ? 1.f : 0.f);  // (opaque: or hipcc re-fuses the two compares)
     return a;
 }
 
