@@ -45,6 +45,8 @@ sys.path.insert(0, ROOT)
 #           32x32x16 tile), "f16x4" = the weight-gradient outer products (hi|lo pairs as adjacent k-slots: 8 fp16 MFMAs per
 #           32x32x32 tile = 4 MFMA-MACs per algorithmic MAC; on the fp32 MFMA under --wgrad-f32 / --exact-f32),
 #           "f32" = v_mfma_f32_32x32x2_f32, "valu" = the 64-wide output layers (plain FMAs).
+ALG_PROPOSAL = {  # k_decode_rays<false,false>: the sampler's proposal pass, sdf head only (estimators.py:22-101)
+    "device_kernel": "k_decode_rays", "bytes_8d": 3 * 4 * 32 * 4, "macs": {"f16x3": 2048 + 4096, "valu": 64}}
 ALG = {
     "tt_render_fwd": {  # k_decode_rays<N,TEX> (+ k_march_fwd): sdf 6208 + feat 10432 + normal chain 6208 = 22848 MAC
         "device_kernel": "k_decode_rays",
@@ -550,6 +552,7 @@ def secondary_workloads(device, inp, steps=5, warmup=2, rc=None):
     # (i) importance-sampled configs[1]
     r1 = tt.find("generative-space-sdf-volume-renderer")(base, geometry=geo, material=mat, background=bgm).to(device)
     r1.train()
+    r1.precision = rc.precision if rc is not None else None
     cache = inp["cache"][:1].detach().clone().requires_grad_(True)
     kw = dict(space_cache=cache, text_embed=torch.zeros(1, 77, 1024), camera_distances=inp["cd"][:1], c2w=inp["c2w"][:1])
     ro, rd, bg = inp["ro"][:1], inp["rd"][:1], inp["bg"]
@@ -573,6 +576,7 @@ def secondary_workloads(device, inp, steps=5, warmup=2, rc=None):
                                     "base_renderer_type": "generative-space-sdf-volume-renderer", "base_renderer": base},
                                    geometry=geo, material=mat, background=bgm).to(device)
     r2.train()
+    r2.base_renderer.precision = rc.precision if rc is not None else None
     P, NV = 2, 4
     gen = torch.Generator().manual_seed(1)
     cache2 = (torch.randn(P, 6, 32, 256, 256, generator=gen) * 0.5).to(device).requires_grad_(True)
@@ -612,6 +616,123 @@ def secondary_workloads(device, inp, steps=5, warmup=2, rc=None):
     return res
 
 
+def run_config2(args, device, rank, world, dist):
+    """BASELINE configs[2]: the renderer side of the distillation inner loop.  Per GPU 8 prompts x 4 views (MVDream-style),
+    128 x 128 rays per view through PatchRenderer (42 x 42 global + 40 x 40 patch rays, patch_renderer.py:49-88, yaml
+    :148-150), the reference's sampler (128 proposal + 64 importance samples -> 193 intervals, estimators.py:22-101), and
+    per STEP the four render + backward passes of one training step (num_parts_training = 4: ...generator.py:410,500,536,
+    yaml :62-63), each on its own space cache (the generator decodes new planes for every part).  Everything through the
+    plugin (registry names, forward signature), fwd + bwd of a G6-style loss on the composited 128 x 128 outputs."""
+    import triplaneturbo_amd as tt
+    from triplaneturbo_amd import ops, synthetic
+    P, NV, H, W, R, PARTS = 8, 4, 128, 128, 256, 4
+    torch.manual_seed(0)
+    geo = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(device)
+    geo.precision = args.precision
+    base = dict(estimator="importance", trainable_variance=False, learned_variance_init=0.4605, num_samples_per_ray=64,
+                num_samples_per_ray_importance=128, near_plane=0.1, far_plane=4.0, randomized=True)
+    mat, bgm = tt.find("no-material")({}), tt.find("solid-color-background")({})
+    r = tt.find("patch-renderer")({"patch_size": 40, "global_downsample": 3,
+                                   "base_renderer_type": "generative-space-sdf-volume-renderer", "base_renderer": base},
+                                  geometry=geo, material=mat, background=bgm).to(device)
+    r.train()
+    r.base_renderer.precision = args.precision
+    gen = torch.Generator().manual_seed(10 + rank)
+    caches = [(torch.randn(P, 6, 32, R, R, generator=gen) * 0.5).to(device).requires_grad_(True) for _ in range(PARTS)]
+    ro, rd, c2w, cd = synthetic.make_cameras(P * NV, H, W)
+    ro, rd, c2w, cd = ro.to(device), rd.to(device), c2w.to(device), cd.to(device)
+    bg = torch.ones(3, device=device)
+    proj = {k: torch.randn(P * NV, H, W, c, generator=gen).to(device) for k, c in
+            (("comp_rgb", 3), ("opacity", 1), ("depth", 1), ("comp_normal_cam_vis", 3))}
+    te = torch.zeros(P, 77, 1024)
+    params = list(geo.parameters())
+
+    def step():
+        for p_ in params:
+            p_.grad = None
+        total = 0.0
+        for part in range(PARTS):
+            caches[part].grad = None
+            out = r(ro, rd, None, bg, space_cache=caches[part], text_embed=te, camera_distances=cd, c2w=c2w)
+            loss = sum((out[k] * v).sum() for k, v in proj.items()) + (out["opacity"] ** 2 + 0.01).sqrt().mean() + \
+                ops.eikonal_loss(out["sdf_grad"])
+            (loss / PARTS).backward()
+            total = total + loss.detach()
+        if world > 1:  # the renderer-side parameters' gradients: one flat all-reduce per step
+            from triplaneturbo_amd.parallel import allreduce_mlp_grads
+            allreduce_mlp_grads(params, dist)
+        return total
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    timer = ops.KernelTimer()
+    ops.set_kernel_timer(timer)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    if rank != 0:
+        return
+    rays_render = P * NV * (42 * 42 + 40 * 40)           # rays marched per render (global + patch)
+    rays_step = rays_render * PARTS
+    S, S_PROP = 193, 128
+    torch.cuda.synchronize()
+    per_step = {}
+    for label, a, b in timer.events:
+        per_step[label] = per_step.get(label, 0.0) + a.elapsed_time(b) / args.steps
+    n_s = rays_step * S
+    kernels = {k: kernel_roofline(k, per_step[k], n_s, args.precision) for k in ALG if k in per_step}
+    if "tt_decode_rays" in per_step:
+        ALG["tt_decode_rays"] = ALG_PROPOSAL
+        kernels["tt_decode_rays"] = kernel_roofline("tt_decode_rays", per_step["tt_decode_rays"], rays_step * S_PROP, args.precision)
+    for k, v in kernels.items():
+        v["launches_per_step"] = sum(1 for lab, _, _ in timer.events if lab == k) // args.steps
+        v["note"] = "sum over the launches of one step (4 parts x 2 renders), samples = rays x 193 (proposal: x 128)"
+    dom = max((k for k in kernels), key=lambda k: kernels[k]["avg_ms"])
+    kd = kernels[dom]
+    roofline = {"kernel": dom, "bound": "mfma" if kd["bound_8d"] == "mfma" else "hbm",
+                "achieved": kd["alg_tflops"] if kd["bound_8d"] == "mfma" else kd["alg_GBs"],
+                "peak": PEAK_F32_TFLOPS if kd["bound_8d"] == "mfma" else PEAK_HBM_GBS,
+                "unit": "TFLOP/s" if kd["bound_8d"] == "mfma" else "GB/s", "frac": kd["frac_8d"],
+                "frac_pipe_mix": kd["frac_pipe_mix"], "avg_kernel_ms": kd["avg_ms"], "traffic": None,
+                "definition": "frac_8d over the summed launches of one step (see --config 1 for the per-launch form, the SQ / "
+                              "PMC counters and the executed-work fractions)"}
+    ms = dt / args.steps * 1e3
+    line = {"metric": "rendered rays/sec (fwd+bwd), BASELINE configs[2]: 8 prompts x 4 views, 128x128 rays, PatchRenderer, "
+                      "193 importance samples, 4 render+backward passes per step",
+            "value": rays_step * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPES[args.precision], "precision": args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: per GPU 8 prompts x 4 views of 128x128 rays through PatchRenderer "
+                                   "(42x42 global + 40x40 patch rays per view = 107 648 rays per render, 193 samples: 128 "
+                                   "proposal + 64 importance), planes (8,6,32,256,256) x 4 caches, one step = the 4 render + "
+                                   "backward passes of a distillation step (num_parts_training = 4)",
+                       "rays_marched_per_render": rays_render, "rays_per_step": rays_step, "image_pixels_per_step": P * NV * H * W * PARTS,
+                       "samples_per_ray": S, "proposal_samples_per_ray": S_PROP, "parallelism": f"dp{world}",
+                       "ms_per_render_fwd_bwd": round(ms / PARTS, 3), "loss": float(loss)},
+            "roofline": roofline, "kernels": kernels,
+            "other_entry_points_ms_per_step": {k: round(v, 4) for k, v in per_step.items() if k not in kernels},
+            "glue_ms": round(ms - sum(per_step.values()), 3), "timed_region_s": round(dt, 3)}
+    if world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline(S=193)
+        cb["sample"] += "; stand-in for configs[2]: the same oracle pass with 193 (uniform) samples per ray -- the CPU cost per ray " \
+                        "does not depend on where the samples sit"
+        line["cpu_baseline"] = cb
+    print(json.dumps(line), flush=True)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -633,10 +754,12 @@ def spawn_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300, help="timed steps (default 300: a ~2.3 s timed region)")
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=1, choices=(1, 3),
-                    help="1 = BASELINE configs[1] per GPU (headline); 3 = configs[3]: 8 prompts x 256x256 rays per GPU")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 300 = a ~2.7 s timed region; --config 2: 20)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 10 (--config 2: 2)")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3),
+                    help="1 = BASELINE configs[1] per GPU (headline); 2 = configs[2]: the distillation loop's renders (8 prompts "
+                         "x 4 views, PatchRenderer, 193 samples, 4 render+backward passes per step); 3 = configs[3]: 8 prompts x "
+                         "256x256 rays per GPU")
     ap.add_argument("--precision", default="split3", choices=("split3", "f32", "split2"),
                     help="MLP products: split3 = fp32-grade 3-piece split on the fp16 pipe (default, the reference's "
                          "precision), f32 = fp32-input MFMA, split2 = the 2-piece fast mode of rounds 2-4")
@@ -654,6 +777,10 @@ def main():
     ap.add_argument("--tile-chunk", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--grad-copies", type=int, default=1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.config == 2 else 300
+    if args.warmup is None:
+        args.warmup = 2 if args.config == 2 else 10
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
         sys.exit(spawn_ranks(args))
@@ -691,6 +818,14 @@ def main():
     from triplaneturbo_amd import functional, ops
     from triplaneturbo_amd.parallel import FlatGradBucket
 
+    if args.exact_f32:
+        args.precision = "f32"
+    if args.config == 2:
+        run_config2(args, device, rank, world, dist)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     R, Hh, Ww, S = 256, 256, 256, 128
     inp = make_inputs(rank, world, device, args.config, R, Hh, Ww, S)
     P = inp["cache"].shape[0]

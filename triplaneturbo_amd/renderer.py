@@ -138,6 +138,10 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         # the plugin equals the reference's (it then runs on the training forward kernels, which are faster than the
         # fused kernel when nothing may be skipped: functional.volume_render).  Not a reference knob, so not in Config.
         self.eval_termination_eps = 0.0
+        # precision of the MLP products (ops.RenderConfig.precision / include/tt_abi.h): None = "split3", the fp32-grade
+        # default (the reference multiplies in fp32, networks.py:91-97); "f32" = fp32-input MFMA; "split2" = the fast mode.
+        # Not a reference knob, so not in Config.
+        self.precision = None
 
     # ------------------------------------------------------------------------------------------
     def _inv_std_value(self) -> float:
@@ -168,7 +172,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         rc = ops.RenderConfig(radius=self.cfg.radius, sdf_bias_radius=float(g.sdf_bias_params),
                               cos_anneal_ratio=float(self.cos_anneal_ratio),
                               rgb_grad_shrink=float(self.rgb_grad_shrink), skip_eps_tex=float(self.grad_skip_eps_tex),
-                              skip_eps_geo=float(self.grad_skip_eps_geo))
+                              skip_eps_geo=float(self.grad_skip_eps_geo), precision=self.precision)
         if self.cfg.trainable_variance:
             # LearnedVariance.forward's value as a graph tensor on the device (renderer :29-35): the optimiser moves the
             # parameter every step, so nothing is read back to the host; rc.inv_std stays a placeholder the kernels ignore
