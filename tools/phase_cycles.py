@@ -71,7 +71,8 @@ names = ["upstream cbar + skip test", "gather e (12 corners)", "park e in LDS", 
 geo_names = ["upstream (d sdf, d sdf_grad) + skip test", "gather f, u (12 corners)", "", "sdf net recompute + reverse chain (5 products)",
              "a1bar = W1 qbar, v", "a2bar = W2 b1bar, dw3 (transpose + VALU)", "", "dW1 outer products",
              "dW2 outer products", "scatter: q staging + corner set-up", "scatter epilogue", "tail",
-             "", "", "", "", "", "", "", ""]
+             "", "", "", "", "", "  (of the epilogue) operands -> registers, next plane's set-up, operand split + MFMAs",
+             "  (of the epilogue) next plane's slot claims", "  (of the epilogue) flush atomics, tag reset, lost references"]
 print(f"texture backward: {buf[12] / n / 1024:.0f} live tile steps per wave per launch, {buf[13] / max(buf[12], 1):.1f} of 32 lanes live on average, {buf[14] / max(buf[12], 1):.1f} with |cbar| > 1e-12")
 tex_pt, geo_pt = 3 * buf[12], buf[36]
 print(f"scatter, texture kernel: {buf[15] / max(tex_pt, 1):.1f} active references per plane-tile, "

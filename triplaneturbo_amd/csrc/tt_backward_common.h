@@ -568,6 +568,23 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
     int* const dummy = tags + 128 + i;
     PlaneRefs rc, rn;
     ClaimState sc, sn;
+#ifdef TT_TUNING  // sub-phase cycles of the epilogue (geometry kernel: st[3..5] = operands+prep / GEMM+claim / flush+reset+lost)
+    unsigned long long sp_t = __builtin_amdgcn_s_memtime();
+#define TT_SUBPHASE(k)                                                    \
+    do {                                                                  \
+        if (st) {                                                         \
+            __builtin_amdgcn_sched_barrier(0);                            \
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+            st[k] += t_now - sp_t;                                        \
+            sp_t = t_now;                                                 \
+            __builtin_amdgcn_sched_barrier(0);                            \
+        }                                                                 \
+    } while (0)
+#else
+#define TT_SUBPHASE(k) \
+    do {               \
+    } while (0)
+#endif
     prep(0, rc);
     sc = scatter_claim<EXACT>(rc, M, tags, dummy, i, st);
     scatter_lost(rc, sc, Qs, Ls, grsrc, i, hi);
@@ -653,7 +670,9 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
                 acc1[r] *= bun;
             }
         }
+        TT_SUBPHASE(3);
         if (pl < 2) sn = scatter_claim<EXACT>(rn, M, tags + 64 * ((pl + 1) & 1), dummy, i, st);
+        TT_SUBPHASE(4);
         // ---- flush: one 128-byte atomic per slot pair, straight from the accumulators (slot of reg 4g+e = LIDX) ----
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -675,6 +694,7 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
             rc = rn;
             sc = sn;
         }
+        TT_SUBPHASE(5);
     }
 }
 
