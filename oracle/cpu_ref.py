@@ -74,6 +74,12 @@ Tensor = torch.Tensor
 #   * nn.Linear: channels in natural order, blocks of 16, block partial sums added first-to-last;
 #   * corners ne, nw, se, sw;  planes (0 + 2) + 1;  samples accumulated in two halves (near half + far half);
 #   * the logistic function in its two-branch fp32 form: 1 / (1 + exp(-x)) for x >= 0, exp(x) / (1 + exp(x)) for x < 0.
+#   alt_order(3)
+#   * nn.Linear: blocks of 4 channels, even blocks first, then the odd ones;  corners sw, nw, se, ne;  planes (1 + 2) + 0;
+#     samples accumulated in chunks of 8 (chunk sums added near-to-far);
+#   * the correctly rounded logistic (as level 1);  F.normalize as x / sqrt(|x|^2) with |x|^2 = x^2 + (y^2 + z^2);
+#   * the sample position o + d t with ONE rounding (evaluated in fp64 and rounded: what a fused multiply-add gives) instead
+#     of a rounded product followed by a rounded sum -- the sample coordinates are where fp32 rounding enters the geometry side.
 # Same operations, same operands, same dtype: the pairwise distances of the three fp32 evaluations are the order /
 # implementation sensitivity of the fp32 math itself on that scene, and tests/parity.py asks of the HIP path
 #     |hip - fp32| <= max(1e-4, 1.5 x the largest of those distances).
@@ -94,7 +100,7 @@ def alt_order(level=1):
 
 def _sigmoid(x: Tensor) -> Tensor:
     """torch.sigmoid(x) -- or, under alt_order() on fp32 input, another valid fp32 logistic (see above)."""
-    if _ALT_ORDER == 1 and x.dtype == torch.float32:
+    if _ALT_ORDER in (1, 3) and x.dtype == torch.float32:
         return torch.sigmoid(x.double()).float()
     if _ALT_ORDER == 2:
         e = torch.exp(-x.abs())
@@ -109,6 +115,9 @@ def _normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
         return x * torch.rsqrt(n2.clamp_min(eps * eps))
     if _ALT_ORDER == 2:
         return x * (1.0 / torch.linalg.norm(x, dim=-1, keepdim=True).clamp_min(eps))
+    if _ALT_ORDER == 3:
+        n2 = x[..., 0:1] ** 2 + (x[..., 1:2] ** 2 + x[..., 2:3] ** 2)
+        return x / n2.sqrt().clamp_min(eps)
     return F.normalize(x, dim=-1, eps=eps)
 
 
@@ -130,9 +139,13 @@ def _linear(x: Tensor, w: Tensor) -> Tensor:
             k0 = max(k1 - 8, 0)
             part = F.linear(x[..., k0:k1].flip(-1), w[:, k0:k1].flip(-1))
             out = part if out is None else out + part
-    else:
+    elif _ALT_ORDER == 2:
         for k0 in range(0, K, 16):  # natural order, blocks of 16 first-to-last
             part = F.linear(x[..., k0:k0 + 16], w[:, k0:k0 + 16])
+            out = part if out is None else out + part
+    else:
+        for k0 in list(range(0, K, 8)) + list(range(4, K, 8)):  # blocks of 4: the even ones, then the odd ones
+            part = F.linear(x[..., k0:k0 + 4], w[:, k0:k0 + 4])
             out = part if out is None else out + part
     return out
 
@@ -224,6 +237,8 @@ def grid_sample_gather(inp: Tensor, grid: Tensor, padding_mode: str = "zeros", a
         corners = corners[::-1]
     elif _ALT_ORDER == 2:
         corners = [corners[1], corners[0], corners[3], corners[2]]
+    elif _ALT_ORDER == 3:
+        corners = [corners[2], corners[0], corners[3], corners[1]]
     for cy, cx, w, inb in corners:
         idx = (cy.clamp(0, H - 1) * W + cx.clamp(0, W - 1)).long()  # (N, M)
         val = torch.gather(flat, 1, idx[..., None].expand(-1, -1, C))
@@ -250,6 +265,8 @@ def sample_from_planes(plane_features: Tensor, coordinates: Tensor, interpolate_
             return (feats[:, 2] + feats[:, 1]) + feats[:, 0]
         if _ALT_ORDER == 2:
             return (feats[:, 0] + feats[:, 2]) + feats[:, 1]
+        if _ALT_ORDER == 3:
+            return (feats[:, 1] + feats[:, 2]) + feats[:, 0]
         return feats.sum(dim=1)
     elif interpolate_feat == "v2":
         return feats.permute(0, 2, 1, 3).reshape(N, M, n_planes * C)
@@ -392,7 +409,10 @@ def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Seq
     ray_indices = torch.arange(n_rays).unsqueeze(-1).expand(-1, S).reshape(-1)
     t_origins = ro[ray_indices]
     t_dirs = rd[ray_indices]
-    positions = t_origins + t_dirs * t_positions
+    if _ALT_ORDER == 3 and t_positions.dtype == torch.float32:  # one rounding, as a fused multiply-add
+        positions = (t_origins.double() + t_dirs.double() * t_positions.double()).float()
+    else:
+        positions = t_origins + t_dirs * t_positions
 
     geo = geometry_forward(positions.reshape(B, -1, 3), cache, sdf_weights, feat_weights,
                            radius=radius, sdf_bias_radius=sdf_bias_radius,
@@ -416,6 +436,12 @@ def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Seq
             return acc
         if _ALT_ORDER == 2 and S > 1:  # near half + far half
             return src[:, :S // 2].sum(dim=1) + src[:, S // 2:].sum(dim=1)
+        if _ALT_ORDER == 3:  # chunks of 8 samples, chunk sums added near-to-far
+            acc = None
+            for k0 in range(0, S, 8):
+                part = src[:, k0:k0 + 8].sum(dim=1)
+                acc = part if acc is None else acc + part
+            return acc
         return src.sum(dim=1)
 
     opacity = accumulate(None)

@@ -39,17 +39,18 @@ PRECISIONS = ["split3", "f32", "split2"]
 # equal sigmoids scaled by inv_std, so two correct fp32 evaluations that merely add in a different order differ by 1e-4 ...
 # 1e-2 in the gradients, and "within 1e-4 of THE fp32 oracle" is then not a property any fp32 implementation can have.
 # Rounds 3-4 inferred that conditioning from the oracle's distance to fp64 (COND32 / COND_K: gone).  Round 5 MEASURES it:
-# the oracle evaluates the same fp32 math twice more in different, documented ways (oracle/cpu_ref.py: alt_order(1) and (2)
-# -- other channel / corner / plane / sample summation orders and two other valid fp32 logistic functions), and the bar is
-#     min(|hip - fp32|, |hip - fp32'|, |hip - fp32''|) <= max(1e-4, ORDER_K x max(|fp32 - fp32'|, |fp32 - fp32''|, |fp32' - fp32''|))
-# per gradient, in relative norm: the HIP gradient must lie within 1e-4 of the fp32 oracle wherever the three fp32 evaluations
-# agree to that (then the three distances coincide: north_star's rtol, unchanged), and where they do not, no further from the
-# nearest of them than 1.5x their own largest mutual distance -- the fp32 math's MEASURED order / implementation sensitivity
+# the oracle evaluates the same fp32 math three more times in different, documented ways (oracle/cpu_ref.py: alt_order(1 .. 3)
+# -- other channel / corner / plane / sample summation orders, other valid fp32 logistic functions and normalisations, a
+# fused-multiply-add sample position), and the bar is
+#     min_j |hip - fp32_j| <= max(1e-4, ORDER_K x max_jk |fp32_j - fp32_k|)            j, k over the four fp32 evaluations
+# in relative norm (left side per gradient; right side the largest over the case's gradients): the HIP gradient must lie within
+# 1e-4 of the fp32 oracle wherever the fp32 evaluations agree to that (then the distances coincide: north_star's rtol,
+# unchanged), and where they do not, no further from the nearest of them than 1.5x their own largest mutual distance -- the fp32 math's MEASURED order / implementation sensitivity
 # on that scene (nothing is inferred from fp64).  The same rule applies element-wise: the fraction of elements outside SURVEY
 # 8(d)'s bar may exceed ELEM_VS_FP32 only by ORDER_K x the fraction on which the fp32 evaluations miss it among themselves.  The FAST mode (split2: ~2^-21.5 per product against fp32's 2^-24) is a tolerance-bounded
 # approximation and is held to FAST_K x that bar in the fuzz (every non-fuzz test keeps the plain 1e-4 for all three modes).
 ORDER_K = 1.5
-FAST_K = 8.0
+FAST_K = 4.0
 KINK_TAU = 2.0 ** -19  # see kink_free_rays
 NAMES = ["space_cache", "sdf.w1", "sdf.w2", "sdf.w3", "feat.v1", "feat.v2", "feat.v3"]
 
@@ -103,8 +104,10 @@ def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-
             rows[n]["fp32_order_sensitivity_elem"] = max(elementwise(evals[i], evals[j])["viol_frac"] for i, j in pairs)
             rows[n]["hip_vs_fp32_alt"] = [rel(a, t) for t in b32a]
     report(case, rows)
+    # the order sensitivity of a CASE is the largest over its gradients: they are driven by the same per-sample upstream
+    # errors (typically one ill-conditioned ray), so the per-gradient values are samples of one scene property
+    sens = max([r.get("fp32_order_sensitivity", 0.0) for r in rows.values()] or [0.0])
     for n, r in rows.items():
-        sens = r.get("fp32_order_sensitivity", 0.0)
         bar = max(tol32, ORDER_K * sens) * (FAST_K if fast else 1.0)
         nearest = min([r["hip_vs_fp32"]] + r.get("hip_vs_fp32_alt", []))
         assert nearest <= bar, (case, n, bar, rows)

@@ -132,7 +132,7 @@ def test_backward_matches_oracle(mods, P, R, n_view, Hh, Ww, S, seed, precision)
     if key not in _ORACLE_CACHE:  # the same four oracle evaluations serve the three precision modes
         a = (cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
         _ORACLE_CACHE[key] = (_oracle_grads(torch.float32, *a)[1:], _oracle_grads(torch.float64, *a)[1:],
-                              [_oracle_grads(torch.float32, *a, alt_order=lv)[2] for lv in (1, 2)])
+                              [_oracle_grads(torch.float32, *a, alt_order=lv)[2] for lv in (1, 2, 3)])
     (l32, g32), (l64, g64), g32a = _ORACLE_CACHE[key]
     assert abs(l_hip - l64) <= max(4 * abs(l32 - l64), 1e-5 * abs(l64))
     # g32_alt: the fp32 oracle's own order / implementation sensitivity, measured (tests/parity.py: ORDER_K) -- case 4 is

@@ -12,6 +12,9 @@ from oracle import cpu_ref as O  # noqa: E402
 import test_gpu_fuzz as F  # noqa: E402
 from test_gpu_backward import KEYS, _hip_grads, _oracle_grads  # noqa: E402
 from parity import rel  # noqa: E402
+from triplaneturbo_amd import _lib  # noqa: E402
+if os.environ.get("TT_USE_TUNING"):
+    _lib.use_tuning_build()
 from triplaneturbo_amd import functional, ops  # noqa: E402
 
 mods = (ops, functional)
@@ -44,7 +47,7 @@ for seed in seeds:
     if os.environ.get("TT_FUZZ_KNOBS"):  # e.g. TT_FUZZ_KNOBS="tile_sb=0,tile_chunk=0"
         for kv in os.environ["TT_FUZZ_KNOBS"].split(","):
             k, v = kv.split("=")
-            kn[k] = type(kn[k])(int(v))
+            kn[k] = type(kn[k])(int(v)) if k in kn else bool(int(v))  # (wgrad_f32=1 / bwd_pair=1: tuning build, TT_USE_TUNING=1)
     if os.environ.get("TT_FUZZ_RC"):  # e.g. TT_FUZZ_RC="inv_std=10"
         for kv in os.environ["TT_FUZZ_RC"].split(","):
             k, v = kv.split("=")
@@ -54,10 +57,10 @@ for seed in seeds:
         keep = kink_free_rays(cache, sw, fw, ro, rd, ts, te, n_view)
         proj = {n: v * keep.view(P * n_view, Hh, Ww, 1).to(v.dtype) for n, v in proj.items()}
     gm = {}
-    for mode in ("split3", "f32", "split2"):
+    for mode in os.environ.get("TT_FUZZ_MODES", "split3,f32,split2").split(","):
         _, _, gm[mode] = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, dict(rck, **dict(kn, precision=mode)))
     _, _, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
-    g32a = [_oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck, alt_order=lv)[2] for lv in (1, 2)]
+    g32a = [_oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck, alt_order=lv)[2] for lv in (1, 2, 3)]
     _, _, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
     verbose = len(seeds) <= 40
     if verbose:
@@ -65,15 +68,16 @@ for seed in seeds:
     for i, n in enumerate(names):
         if float(g64[i].abs().max()) == 0:
             continue
-        d = {m: rel(gm[m][i], g32[i]) for m in gm}
-        sens = max(rel(g32a[0][i], g32[i]), rel(g32a[1][i], g32[i]), rel(g32a[0][i], g32a[1][i]))
+        d = {m: min(rel(gm[m][i], e[i]) for e in [g32] + g32a) for m in gm}  # nearest of the fp32 evaluations
+        ev = [g32] + g32a
+        sens = max(rel(ev[k][i], ev[j][i]) for k in range(len(ev)) for j in range(k))
         o64 = rel(g32[i], g64[i])
         bar = max(1e-4, 1.5 * sens)
         for m in gm:
             if d[m] > 1e-4:
                 worst[(seed, n, m)] = (d[m] / bar, d[m], sens, o64, rel(gm[m][i], g64[i]))
         if verbose:
-            print(f"   {n:12s} vs fp32 oracle: split3 {d['split3']:.2e} f32 {d['f32']:.2e} split2 {d['split2']:.2e} | fp32 order "
+            print(f"   {n:12s} vs fp32 oracle: " + " ".join(f"{m} {d[m]:.2e}" for m in d) + " | fp32 order "
                   f"sensitivity {sens:.2e}  fp32 vs fp64 {o64:.2e}")
 print("gradients further than 1e-4 from the fp32 oracle (mode; ratio to the bar max(1e-4, 1.5 x order sensitivity)):")
 for k, v in sorted(worst.items(), key=lambda kv: -kv[1][0]):
