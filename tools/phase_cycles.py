@@ -81,7 +81,7 @@ print(f"scatter, geometry kernel: {buf[34] / max(geo_pt, 1):.1f} active referenc
       f"{100.0 * buf[35] / max(buf[34], 1):.1f} % of them lost their slot (direct path)")
 buf[12] = buf[13] = buf[14] = buf[15] = buf[16] = buf[34] = buf[35] = buf[36] = 0
 for title, ofs, nms in (("k_decode_bwd_tex", 0, names), ("k_decode_bwd_geo", 20, geo_names)):
-    tot = sum(buf[ofs:ofs + 20])
+    tot = sum(buf[ofs:ofs + (17 if ofs == 20 else 20)])  # (geometry slots 17..19 are sub-phases OF the epilogue, not extra time)
     print(f"== {title}: {tot / n / 1024 / 1e6:.2f} M shader cycles per wave ==")
     for k, nm in enumerate(nms):
         if nm:

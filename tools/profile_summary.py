@@ -47,10 +47,11 @@ m = lambda k, c: acc[k][c] / cnt[k][c] if cnt[k][c] else float("nan")
 L += ["", "## SQ counters (separate --pmc pass), per launch", "",
       f"MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (duration x {CLOCK_GHZ} GHz x {SIMDS} SIMDs)  [clock assumed under "
       "load]; wave life = SQ_WAVE_CYCLES x 4 / SQ_WAVES / (SQ_BUSY_CYCLES / 32 SEs): the average fraction of the "
-      "kernel a wave is resident (load balance; counters in quad-cycles / per-SE cycles).  The forward decode and the "
-      "geometry backward run their mat-vec chains as split-fp16 MFMAs (3 x v_mfma_f32_32x32x16_f16 = 96 busy cycles per "
-      "16-deep k-step instead of 8 x v_mfma_f32_32x32x2_f32 = 512), so their MfmaUtil is LOW BY DESIGN: the same "
-      "algorithmic FLOPs need 5.3x less matrix-pipe time.", "",
+      "kernel a wave is resident (load balance; counters in quad-cycles / per-SE cycles).  The decode kernels (template argument 2 = the default three-piece "
+      "precision mode, 0 = two pieces, 1 = fp32 MFMA) run their mat-vec chains as split-fp16 MFMAs: 6 (three-piece) or 3 "
+      "(two-piece) x v_mfma_f32_32x32x16_f16 = 192 / 96 busy cycles per 16-deep k-step instead of 8 x "
+      "v_mfma_f32_32x32x2_f32 = 512, so their MfmaUtil is LOW BY DESIGN: the same algorithmic FLOPs need 2.7x / 5.3x less "
+      "matrix-pipe time (the bench line's `modes.f32.kernels.*.sq.mfma_util` has the fp32-MFMA mode: 0.62 - 0.67).", "",
       "| kernel | avg us | MFMA busy cycles | MFMA busy ms / SIMD | MfmaUtil | wave life | WAIT_ANY/WAVE | WAIT_INST/WAVE |",
       "|---|---|---|---|---|---|---|---|"]
 for k in sorted(acc, key=lambda k: -avg_us.get(k, 0)):
