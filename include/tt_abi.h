@@ -65,7 +65,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 16
+#define TT_ABI_VERSION 17
 #define TT_CHANNELS 32 /* feature channels per plane (space_generator output_dim/2, yaml :95) */
 #define TT_HIDDEN 64   /* mlp_network_config.n_neurons */
 
@@ -162,6 +162,12 @@ typedef struct {
 #define TT_R_SPLIT2 32
 #define TT_R_SPLIT3 64
 
+/* use_volsdf = True of the reference (threestudio/models/renderers/neus_volume_renderer.py:19-23,:95-96 and
+ * generative_space_sdf_volume_renderer.py:286-287): alpha = |t_end - t_start| x density(sdf), density = k (0.5 + 0.5
+ * sign(sdf) expm1(-|sdf| k)) with k = inv_std clamped to [0, 80]; NOT clipped to [0,1] and independent of the normal and of
+ * cos_anneal_ratio.  Honoured by tt_render_forward / _backward, the march entry points and the fused eval render. */
+#define TT_R_VOLSDF 128
+
 #define TT_R_WGRAD_F32 4  /* TUNING BUILD ONLY (-DTT_TUNING; the product library returns TT_ERR_UNSUPPORTED): backward
                              weight-gradient outer products on the fp32-input MFMA instead of split-fp16 products with
                              per-launch operand scales; the round-2 A/B switch, TT_R_SPLIT2 only */
@@ -227,6 +233,9 @@ int tt_decode_rays(const float* packed, const tt_mlp_weights* w, const float* ra
  * Under either one the empirical distribution of the resampled edges follows the proposal cdf within one cell
  * (tests/test_gpu_sampler.py checks that against the cdf itself, not against a restatement of the kernel). */
 enum tt_sample_placement { TT_PLACE_TT = 0, TT_PLACE_CENTER = 1 };
+/* OR-ed into tt_sample_importance's `placement`: the proposal density is the VolSDF density of TT_R_VOLSDF (renderer
+ * :286-287) instead of the fixed-step NeuS density (:288-297) */
+#define TT_PLACE_VOLSDF 0x100
 
 /* Level-0 sample intervals from the uniform cdf: edges s_k = u_k of `placement` (jitter (n_rays, n+1), U[0,1), or
  * null = deterministic), t = s*far + (1-s)*near (_transform_stot "uniform", estimators.py:104-118);
@@ -235,7 +244,8 @@ int tt_sample_uniform(int64_t n_rays, int32_t n_samples, float near_plane, float
                       int32_t placement, float* t_starts, float* t_ends, void* stream);
 
 /* Importance resampling of one proposal level.  In: proposal intervals t_starts/t_ends (n_rays, K) and the sdf
- * (n_rays, K) at their mid-points (tt_decode_rays, flags = 0).  sigma = NeuS alpha over a fixed step / step,
+ * (n_rays, K) at their mid-points (tt_decode_rays, flags = 0).  sigma = NeuS alpha over a fixed step / step (or the
+ * VolSDF density: placement | TT_PLACE_VOLSDF),
  * T = exp(-exclusive_cumsum(sigma dt)), cdf = 1 - [T, 0]; F + 1 fine edges at the u_j of `placement` (u_jitter
  * (n_rays, F+1), U[0,1), or null = deterministic) through the piecewise-linear inverse cdf; out = the K + F + 2
  * edges merged in increasing order as out_t_starts/out_t_ends (n_rays, K + F + 1).  inv_std_dev: null, or a device scalar

@@ -343,9 +343,20 @@ def geometry_forward(points: Tensor, space_cache: Tensor, sdf_weights: Sequence[
 # --------------------------------------------------------------------------
 # NeuS alpha + ray marching
 # --------------------------------------------------------------------------
+def volsdf_density(sdf: Tensor, inv_std) -> Tensor:
+    """threestudio/models/renderers/neus_volume_renderer.py:19-23: the VolSDF Laplace-cdf density, inv_std clamped to [0, 80]."""
+    inv_std = torch.as_tensor(inv_std, dtype=sdf.dtype).clamp(0.0, 80.0)
+    beta = 1 / inv_std
+    alpha = inv_std
+    return alpha * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+
 def get_alpha(sdf: Tensor, normal: Tensor, dirs: Tensor, dists: Tensor, inv_std: float,
-              cos_anneal_ratio: float = 1.0) -> Tensor:
-    """threestudio/models/renderers/neus_volume_renderer.py:93-117 (use_volsdf=False)."""
+              cos_anneal_ratio: float = 1.0, use_volsdf: bool = False) -> Tensor:
+    """threestudio/models/renderers/neus_volume_renderer.py:93-117 (use_volsdf=True: :95-96, alpha = |dists| x density,
+    NOT clipped, independent of the normal)."""
+    if use_volsdf:
+        return torch.abs(dists.detach()) * volsdf_density(sdf, inv_std)
     true_cos = (dirs * normal).sum(-1, keepdim=True)
     iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio)
                  + F.relu(-true_cos) * cos_anneal_ratio)
@@ -358,8 +369,10 @@ def get_alpha(sdf: Tensor, normal: Tensor, dirs: Tensor, dists: Tensor, inv_std:
     return ((p + 1e-5) / (c + 1e-5)).clip(0.0, 1.0)
 
 
-def proposal_density(sdf: Tensor, inv_std: float, render_step_size: float) -> Tensor:
-    """generative_space_sdf_volume_renderer.py:288-297 (fixed-step NeuS density of the proposal pass)."""
+def proposal_density(sdf: Tensor, inv_std: float, render_step_size: float, use_volsdf: bool = False) -> Tensor:
+    """generative_space_sdf_volume_renderer.py:286-297 (fixed-step NeuS density of the proposal pass; use_volsdf: :286-287)."""
+    if use_volsdf:
+        return volsdf_density(sdf, inv_std)
     estimated_next_sdf = sdf - render_step_size * 0.5
     estimated_prev_sdf = sdf + render_step_size * 0.5
     prev_cdf = _sigmoid(estimated_prev_sdf * inv_std)
@@ -386,7 +399,7 @@ def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Seq
            bg_color: Tensor, camera_distances: Tensor, c2w: Tensor,
            inv_std: float = 100.0, radius: float = 1.0, sdf_bias_radius: float = 0.5,
            cos_anneal_ratio: float = 1.0, rgb_grad_shrink: float = 1.0,
-           create_graph: bool = True, training: bool = True) -> Dict[str, Tensor]:
+           create_graph: bool = True, training: bool = True, use_volsdf: bool = False) -> Dict[str, Tensor]:
     """GenerativeSpaceSDFVolumeRenderer._forward for explicit sample intervals
     (generative_space_sdf_volume_renderer.py:214-238, 326-546).
 
@@ -421,7 +434,7 @@ def render(space_cache: Tensor, sdf_weights: Sequence[Tensor], feat_weights: Seq
     if rgb_grad_shrink != 1.0:  # :397-400
         rgb_fg_all = rgb_grad_shrink * rgb_fg_all + (1.0 - rgb_grad_shrink) * rgb_fg_all.detach()
 
-    alpha = get_alpha(geo["sdf"], geo["normal"], t_dirs, t_intervals, inv_std, cos_anneal_ratio)
+    alpha = get_alpha(geo["sdf"], geo["normal"], t_dirs, t_intervals, inv_std, cos_anneal_ratio, use_volsdf)
     weights2d, trans2d = render_weight_from_alpha(alpha.reshape(n_rays, S))
     weights = weights2d.reshape(-1, 1)
 

@@ -305,6 +305,52 @@ def main():
     print("wrote reference_renderer.npz:", len(res), "arrays; f64 loss", float(res["f64_loss"]),
           "opacity range", res["f64_opacity"].min(), res["f64_opacity"].max())
 
+    # ---------------- use_volsdf=True (neus_volume_renderer.py:19-23,95-96; renderer :286-287): a file of its own ----------
+    # (round 5; reference_renderer.npz above is untouched.)  learned_variance_init = 0.2 -> inv_std = e^2 = 7.39: with the
+    # fixture's interval lengths alpha = |dists| x density stays below 1, as in a sane training run (the reference does not
+    # clip it); the adversarial get_alpha / density vectors below also cross the clamp at 80.
+    vres = {}
+    vcfg = dict(base_cfg, use_volsdf=True, learned_variance_init=0.2)
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        torch.set_default_dtype(dt)
+        cache = T(k["cache"], dt).requires_grad_(True)
+        sw = [T(k[f"sdf_w{i}"], dt).requires_grad_(True) for i in range(3)]
+        fw = [T(k[f"feat_w{i}"], dt).requires_grad_(True) for i in range(3)]
+        geo = OracleGeometry(sw, fw)
+        mat = threestudio.find("no-material")(dict(color_activation="sigmoid-mipnerf"))
+        rend = threestudio.find("generative-space-sdf-volume-renderer")(vcfg, geometry=geo, material=mat,
+                                                                        background=WhiteBackground())
+        rend.variance._inv_std.data = rend.variance._inv_std.data.to(dt)
+        rend.train()
+        rend.update_step(0, 0)
+        ro, rd = T(k["rays_o"], dt), T(k["rays_d"], dt)
+        Est.intervals = (T(k["t_starts"], dt), T(k["t_ends"], dt))
+        out = rend(ro, rd, torch.zeros(ro.shape[0], 3, dtype=dt), bg_color=T(k["bg"], dt), space_cache=cache,
+                   text_embed=torch.zeros(cache.shape[0], 77, 4, dtype=dt), camera_distances=T(k["cam_d"], dt),
+                   c2w=T(k["c2w"], dt))
+        proj = {n[5:]: T(v, dt) for n, v in k.items() if n.startswith("proj_")}
+        loss = O.synthetic_loss(out, proj)
+        grads = torch.autograd.grad(loss, [cache] + sw + fw)
+        for key in keys_img + ("weights", "sdf", "features", "sdf_grad"):
+            vres[f"{tag}_{key}"] = out[key].detach().numpy()
+        vres[f"{tag}_inv_std"] = out["inv_std"].detach().numpy()
+        vres[f"{tag}_prop_density"] = Est.last_density.detach().numpy()
+        vres[f"{tag}_loss"] = loss.detach().numpy()
+        vres[f"{tag}_g_cache"] = grads[0].numpy()
+        for i in range(3):
+            vres[f"{tag}_g_sdf_w{i}"] = grads[1 + i].numpy()
+            vres[f"{tag}_g_feat_w{i}"] = grads[4 + i].numpy()
+        if tag == "f64":
+            from threestudio.models.renderers.neus_volume_renderer import volsdf_density
+            sdf = T(res["ga_sdf"], dt)
+            vres["ga_alpha"] = rend.get_alpha(sdf, T(res["ga_normal"], dt), T(res["ga_dirs"], dt), T(res["ga_dists"], dt)).detach().numpy()
+            for inv in (7.0, 80.0, 100.0):  # the last one is clamped to 80 by the reference
+                vres[f"density_{inv}"] = volsdf_density(sdf, torch.tensor(inv, dtype=dt)).numpy()
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "reference_renderer_volsdf.npz"), **vres)
+    print("wrote reference_renderer_volsdf.npz:", len(vres), "arrays; f64 loss", float(vres["f64_loss"]),
+          "max alpha-based weight", vres["f64_weights"].max(), "opacity range", vres["f64_opacity"].min(), vres["f64_opacity"].max())
+
 
 if __name__ == "__main__":
     main()

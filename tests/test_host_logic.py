@@ -70,10 +70,12 @@ def test_renderer_construction_and_schedules():
     _, _, _, c = _modules({"trainable_variance": True})  # the reference class default (renderer :53,82): a trained parameter
     rt = tt.find("generative-space-sdf-volume-renderer")(c, geometry=g, material=m, background=b)
     assert rt.variance._inv_std.requires_grad and not r.variance._inv_std.requires_grad
-    for bad in ({"estimator": "occgrid"}, {"use_volsdf": True}):
-        _, _, _, c = _modules(bad)
-        with pytest.raises(NotImplementedError):
-            tt.find("generative-space-sdf-volume-renderer")(c, geometry=g, material=m, background=b)
+    _, _, _, c = _modules({"estimator": "occgrid"})
+    with pytest.raises(NotImplementedError):
+        tt.find("generative-space-sdf-volume-renderer")(c, geometry=g, material=m, background=b)
+    _, _, _, c = _modules({"use_volsdf": True})  # neus_volume_renderer.py:95-96 -> TT_R_VOLSDF (tests/test_volsdf.py)
+    rv = tt.find("generative-space-sdf-volume-renderer")(c, geometry=g, material=m, background=b)
+    assert rv._render_config().use_volsdf and not r._render_config().use_volsdf
     p = tt.find("patch-renderer")({"patch_size": 40, "global_downsample": 3,
                                    "base_renderer_type": "generative-space-sdf-volume-renderer",
                                    "base_renderer": cfg}, geometry=g, material=m, background=b)
@@ -177,7 +179,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     lib.tt_abi_version.restype = ctypes.c_int
     lib.tt_strerror.restype = ctypes.c_char_p
-    assert lib.tt_abi_version() == _lib._expected_abi() == 16
+    assert lib.tt_abi_version() == _lib._expected_abi() == 17
     assert b"bad argument" in lib.tt_strerror(-1)
     # the binary carries the hash of the sources + flags it was built from, and that is what "up to date" means
     lib.tt_source_hash.restype = ctypes.c_char_p

@@ -1,0 +1,263 @@
+"""use_volsdf=True (threestudio/models/renderers/neus_volume_renderer.py:19-23,:95-96; generative_space_sdf_volume_renderer
+.py:286-287): alpha = |dists| x VolSDF density, unclipped, independent of the normal.
+
+CPU half: the oracle against vectors produced by RUNNING the reference's renderer classes with use_volsdf=True
+(tests/golden/make_golden_renderer.py -> reference_renderer_volsdf.npz; learned_variance_init = 0.2 so inv_std = e^2, some
+alphas above 1 -- the reference does not clip them -- and adversarial get_alpha / density vectors crossing the clamp at 80).
+GPU half: the HIP path (TT_R_VOLSDF / TT_PLACE_VOLSDF) against the same vectors and against the oracle."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref as O
+from parity import PRECISIONS, check_grads
+
+INV_STD = math.exp(10 * 0.2)  # LearnedVariance: exp(10 * learned_variance_init)
+
+
+def T(a, dt=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t if dt is None else t.to(dt)
+
+
+@pytest.fixture(scope="module")
+def vec(golden_dir):
+    return (dict(np.load(os.path.join(golden_dir, "reference_renderer_volsdf.npz"))),
+            dict(np.load(os.path.join(golden_dir, "reference_renderer.npz"))),
+            dict(np.load(os.path.join(golden_dir, "render_small.npz"))))
+
+
+IMG = ("comp_rgb", "comp_rgb_fg", "comp_rgb_bg", "opacity", "depth", "z_variance", "disparity", "comp_normal",
+       "comp_normal_cam_vis", "comp_normal_cam_vis_white")
+GN = ["g_cache"] + [f"g_sdf_w{i}" for i in range(3)] + [f"g_feat_w{i}" for i in range(3)]
+
+
+# ------------------------------------------------------------------ CPU: oracle vs the reference's own results
+@pytest.mark.parametrize("tag,dt,tol", [("f64", torch.float64, 1e-12), ("f32", torch.float32, 2e-6)])
+def test_oracle_volsdf_render_and_gradients_equal_the_reference_renderer(vec, tag, dt, tol):
+    ref, _, k = vec
+    cache = T(k["cache"], dt).requires_grad_(True)
+    sw = [T(k[f"sdf_w{i}"], dt).requires_grad_(True) for i in range(3)]
+    fw = [T(k[f"feat_w{i}"], dt).requires_grad_(True) for i in range(3)]
+    out = O.render(cache, sw, fw, T(k["rays_o"], dt), T(k["rays_d"], dt), T(k["t_starts"], dt), T(k["t_ends"], dt),
+                   T(k["bg"], dt), T(k["cam_d"], dt), T(k["c2w"], dt), inv_std=float(ref[f"{tag}_inv_std"]),
+                   rgb_grad_shrink=0.5, use_volsdf=True)
+    assert abs(float(ref["f64_inv_std"]) - INV_STD) < 1e-9
+    for key in IMG + ("weights", "sdf", "features", "sdf_grad"):
+        want = T(ref[f"{tag}_{key}"])
+        got = out[key].detach().reshape(want.shape)
+        assert (got - want).abs().max().item() <= tol * max(want.abs().max().item(), 1.0), key
+    assert float(ref["f64_weights"].max()) > 1.0  # the fixture does exercise an unclipped alpha
+    proj = {n[5:]: T(v, dt) for n, v in k.items() if n.startswith("proj_")}
+    loss = O.synthetic_loss(out, proj)
+    assert abs(loss.item() - float(ref[f"{tag}_loss"])) <= tol * abs(float(ref[f"{tag}_loss"])) * 4
+    for n, g in zip(GN, torch.autograd.grad(loss, [cache] + sw + fw)):
+        want = T(ref[f"{tag}_{n}"])
+        assert ((g - want).norm() / want.norm()).item() <= tol * 10, n
+
+
+def test_oracle_volsdf_alpha_and_density_known_answers(vec):
+    ref, base, k = vec
+    d = torch.float64
+    sdf = T(base["ga_sdf"], d)
+    a = O.get_alpha(sdf, T(base["ga_normal"], d), T(base["ga_dirs"], d), T(base["ga_dists"], d), INV_STD, use_volsdf=True)
+    torch.testing.assert_close(a, T(ref["ga_alpha"]), rtol=1e-11, atol=1e-13)
+    for inv in (7.0, 80.0, 100.0):
+        torch.testing.assert_close(O.volsdf_density(sdf, inv), T(ref[f"density_{inv}"]), rtol=1e-12, atol=1e-14)
+    assert np.array_equal(ref["density_80.0"], ref["density_100.0"])  # the clamp at 80 (:20)
+    n_rays, S = k["t_starts"].shape
+    dens = O.proposal_density(T(ref["f64_sdf"], d).reshape(n_rays, S), INV_STD, 1.0, use_volsdf=True)
+    torch.testing.assert_close(dens, T(ref["f64_prop_density"]), rtol=1e-11, atol=1e-12)
+
+
+# ------------------------------------------------------------------ GPU: the HIP path
+KEYS = ("comp_rgb", "opacity", "depth", "z_variance", "disparity", "comp_normal", "comp_normal_cam_vis")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_hip_volsdf_render_and_gradients_equal_the_reference_renderer(vec, precision):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from triplaneturbo_amd import functional, ops
+    ref, _, k = vec
+    dev = "cuda"
+    c = T(k["cache"]).to(dev).requires_grad_(True)
+    sw = [T(k[f"sdf_w{i}"]).to(dev).requires_grad_(True) for i in range(3)]
+    fw = [T(k[f"feat_w{i}"]).to(dev).requires_grad_(True) for i in range(3)]
+    rc = ops.RenderConfig(inv_std=float(ref["f32_inv_std"]), rgb_grad_shrink=0.5, precision=precision, use_volsdf=True)
+    g = lambda n: T(k[n]).to(dev)
+    out = functional.volume_render(c, sw, fw, g("rays_o"), g("rays_d"), g("t_starts"), g("t_ends"), g("bg"), g("cam_d"),
+                                   g("c2w"), rc, training=True)
+    for key in KEYS + ("comp_normal_cam_vis_white", "weights", "sdf", "features", "sdf_grad"):
+        want = T(ref[f"f64_{key}"])
+        got = out[key].detach().cpu().double().reshape(want.shape)
+        e32 = (T(ref[f"f32_{key}"]).double() - want).abs().max().item()
+        assert (got - want).abs().max().item() <= max(4 * e32, 2e-5), key
+    loss = O.synthetic_loss(out, {n: g(f"proj_{n}") for n in KEYS})
+    assert abs(loss.item() - float(ref["f64_loss"])) <= 1e-4 * abs(float(ref["f64_loss"])) + 1e-4
+    grads = [t.cpu() for t in torch.autograd.grad(loss, [c] + sw + fw)]
+    print(check_grads(f"volsdf golden case vs the reference renderer's own gradients [{precision}]", grads,
+                      [T(ref[f"f32_{n}"]) for n in GN], [T(ref[f"f64_{n}"]) for n in GN], fast=precision == "split2"))
+
+
+def _march_inputs(n_rays, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    rd = F.normalize(torch.randn(n_rays, 3, generator=g), dim=-1)
+    edges = torch.sort(torch.rand(n_rays, S + 1, generator=g) * 3.5 + 0.1, dim=1).values
+    sdf = torch.randn(n_rays * S, 1, generator=g) * 0.3
+    sdf[::13] = 0.0  # sign(0) = 0: density k / 2, zero derivative w.r.t. the sdf
+    return (rd, edges[:, :-1].contiguous(), edges[:, 1:].contiguous(), sdf, torch.randn(n_rays * S, 3, generator=g),
+            torch.randn(n_rays * S, 3, generator=g) * 2)
+
+
+def _oracle_march(rd, ts, te, sdf, sdf_grad, feat, inv_std):
+    n_rays, S = ts.shape
+    tm = ((ts + te) / 2.0).reshape(-1, 1)
+    ridx = torch.arange(n_rays).unsqueeze(-1).expand(-1, S).reshape(-1)
+    normal = F.normalize(sdf_grad, dim=-1)
+    alpha = O.get_alpha(sdf, normal, rd[ridx], (te - ts).reshape(-1, 1), inv_std, 0.3, use_volsdf=True)
+    w2, tr2 = O.render_weight_from_alpha(alpha.reshape(n_rays, S))
+    w = w2.reshape(-1, 1)
+    acc = lambda v: (w if v is None else w * v).reshape(n_rays, S, -1).sum(dim=1)
+    depth = acc(tm)
+    return {"opacity": acc(None), "depth": depth, "rgb_fg": acc(O.sigmoid_mipnerf(feat)),
+            "z_variance": acc((tm - depth[ridx]) ** 2), "normal_acc": acc(normal), "weights": w}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,inv_std", [(7, 3.0), (64, 6.0), (193, 12.0), (300, 20.0), (65, 95.0)])
+def test_hip_volsdf_march_forward_backward_and_inv_std_gradient(S, inv_std):
+    """The march alone with TT_R_VOLSDF, all kernel variants (register-resident passes and streaming), including
+    d loss / d inv_std (inside the clamp [0, 80], and exactly 0 above it: inv_std = 95)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from triplaneturbo_amd import ops
+    n_rays = 29
+    x32 = _march_inputs(n_rays, S, 300 + S)
+    dev = [t.cuda() for t in x32]
+    rc = ops.RenderConfig(inv_std=inv_std, cos_anneal_ratio=0.3, use_volsdf=True)
+    out = ops.march_forward_raw(*dev, rc)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        x = [t.to(dt) for t in x32]
+        for t in x[3:]:
+            t.requires_grad_(True)
+        kk = torch.tensor(inv_std, dtype=dt, requires_grad=True)
+        o = _oracle_march(*x, kk)
+        g = torch.Generator().manual_seed(5)
+        ups = {n: torch.randn(v.shape, generator=g).to(dt) for n, v in o.items()}
+        loss = sum((o[n] * ups[n]).sum() for n in ups)
+        ref[dt] = (o, ups, torch.autograd.grad(loss, x[3:5] + [kk]))
+    o32, _, g32 = ref[torch.float32]
+    o64, ups, g64 = ref[torch.float64]
+    for n in o64:
+        e_hip = (out[n].cpu().double() - o64[n].detach()).abs().max().item()
+        e_cpu = (o32[n].detach().double() - o64[n].detach()).abs().max().item()
+        scale = max(1.0, o64[n].detach().abs().max().item())
+        assert e_hip <= max(4 * e_cpu, 2e-6 * scale), (n, S, e_hip, e_cpu)
+    u = {n: v.float().cuda() for n, v in ups.items()}
+    gk = torch.zeros(n_rays, device="cuda")
+    ws = ops.march_backward_raw(dev[0], dev[1], dev[2], out, dev[3], dev[4], dev[5], rc, g_opacity=u["opacity"],
+                                g_depth=u["depth"], g_rgb_fg=u["rgb_fg"], g_z_variance=u["z_variance"],
+                                g_normal_acc=u["normal_acc"], g_weights=u["weights"], g_inv_std_rays=gk)
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    got, want = ws.cpu().double(), torch.cat([g64[0], g64[1]], dim=1)
+    want32 = torch.cat([g32[0], g32[1]], dim=1).double()
+    assert rel(got, want) <= max(1e-4, 3 * rel(want32, want)), S
+    zero = (x32[3] == 0).reshape(-1)
+    assert got[zero, 0].abs().max().item() <= 1e-30 + want[zero, 0].abs().max().item()  # autograd: exactly 0 at sdf = 0
+    gk_sum = gk.double().sum().item()
+    if inv_std > 80.0:
+        assert gk_sum == 0.0 and g64[2].item() == 0.0
+    else:
+        assert abs(gk_sum - g64[2].item()) <= max(1e-4, 3 * abs(g32[2].item() - g64[2].item()) / abs(g64[2].item())) * abs(
+            g64[2].item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("placement", ["tt", "center"])
+def test_hip_volsdf_proposal_density_drives_the_importance_sampler(placement):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from triplaneturbo_amd import ops, sampler
+
+    def sdf_fn(ts, te):
+        tm = (ts + te) / 2
+        return 0.4 * torch.cos(3.0 * tm) + 0.1 * (tm - 1.5)
+
+    n_rays, K, Fn, inv_std, step = 23, 128, 64, 9.0, 1.732 * 2 / 64
+    a = sampler.importance_sampling(sdf_fn, n_rays, K, Fn, 0.1, 4.0, inv_std, step, device="cuda", placement=placement,
+                                    use_volsdf=True)
+    neus = sampler.importance_sampling(sdf_fn, n_rays, K, Fn, 0.1, 4.0, inv_std, step, device="cuda", placement=placement)
+    assert not torch.equal(a[0], neus[0])  # the switch reaches the kernel
+
+    def oracle(dt):
+        ts, te = O.uniform_intervals(n_rays, K, 0.1, 4.0, dt, placement, None)
+        t_vals = torch.cat([ts, te[:, -1:]], dim=1)
+        sd = O.proposal_density(sdf_fn(ts, te), inv_std, step, use_volsdf=True) * (te - ts)
+        excl = torch.cumsum(torch.cat([torch.zeros_like(sd[:, :1]), sd[:, :-1]], dim=1), dim=1)
+        cdfs = 1.0 - torch.cat([torch.exp(-excl), torch.zeros_like(sd[:, :1])], dim=1)
+        t_all, _ = torch.sort(torch.cat([t_vals, O.importance_resample(t_vals, cdfs, Fn, placement, None)], dim=1), dim=1)
+        return t_all[:, :-1], t_all[:, 1:]
+
+    b, b64 = oracle(torch.float32), oracle(torch.float64)
+    ts, te = a[0].cpu(), a[1].cpu()
+    assert (te >= ts).all() and (ts[:, 1:] == te[:, :-1]).all()
+    for got, w32, w64 in ((ts, b[0], b64[0]), (te, b[1], b64[1])):
+        e_hip, e_cpu = (got.double() - w64).abs(), (w32.double() - w64).abs()
+        bad = e_hip > torch.clamp(4 * e_cpu.max(), min=2e-5)
+        assert bad.float().mean().item() <= 0.002, (bad.sum().item(), e_hip.max().item(), e_cpu.max().item())
+
+
+@pytest.mark.gpu
+def test_renderer_module_accepts_use_volsdf_and_trains_the_variance():
+    """The plugin boundary: GenerativeSpaceSDFVolumeRenderer(use_volsdf=True) samples with the VolSDF proposal density,
+    renders, and returns d loss / d variance equal to autograd through the oracle with the parameter as a leaf."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import triplaneturbo_amd as tt
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    g = tt.find("few-step-triplane-dual-stable-diffusion")({}).to(dev)
+    m, b = tt.find("no-material")({}), tt.find("solid-color-background")({})
+    r = tt.find("generative-space-sdf-volume-renderer")(
+        dict(estimator="importance", learned_variance_init=0.2, num_samples_per_ray=16, num_samples_per_ray_importance=32,
+             near_plane=0.1, far_plane=4.0, trainable_variance=True, use_volsdf=True), geometry=g, material=m,
+        background=b).to(dev)
+    r.train()
+    gen = torch.Generator().manual_seed(5)
+    P, n_view, Hh, Ww, S = 1, 2, 5, 7, 40
+    cache0 = torch.randn(P, 6, 32, 32, 32, generator=gen) * 0.5
+    ro, rd, c2w, cd = O.make_cameras(P * n_view, Hh, Ww)
+    ts, te = O.uniform_intervals(P * n_view * Hh * Ww, S, 0.3, 3.2)
+    proj = {k: torch.randn(P * n_view, Hh, Ww, c, generator=gen) for k, c in (("comp_rgb", 3), ("opacity", 1), ("depth", 1))}
+    kw = dict(space_cache=cache0.to(dev).requires_grad_(True), text_embed=torch.zeros(P, 77, 1024),
+              camera_distances=cd.to(dev), c2w=c2w.to(dev))
+    # sampler on (no t_starts): runs the VolSDF proposal density end to end
+    with torch.no_grad():
+        o = r(ro.to(dev), rd.to(dev), None, torch.ones(3, device=dev), **kw)
+    assert o["comp_rgb"].shape == (P * n_view, Hh, Ww, 3) and torch.isfinite(o["comp_rgb"]).all()
+    out = r(ro.to(dev), rd.to(dev), None, torch.ones(3, device=dev), t_starts=ts.to(dev), t_ends=te.to(dev), **kw)
+    loss = O.synthetic_loss(out, {k: v.to(dev) for k, v in proj.items()})
+    loss.backward()
+    gp = r.variance._inv_std.grad.item()
+    sw, fw = g.mlp_weights()
+    sw, fw = [w.detach().cpu() for w in sw], [w.detach().cpu() for w in fw]
+
+    def run_oracle(dtype):
+        p = torch.tensor(0.2, dtype=dtype, requires_grad=True)
+        inv_std = torch.exp(p * 10.0).clamp(1.0e-6, 1.0e6)
+        oo = O.render(cache0.to(dtype), [w.to(dtype) for w in sw], [w.to(dtype) for w in fw], ro.to(dtype), rd.to(dtype),
+                      ts.to(dtype), te.to(dtype), torch.ones(3, dtype=dtype), cd.to(dtype), c2w.to(dtype), inv_std=inv_std,
+                      use_volsdf=True)
+        ll = O.synthetic_loss(oo, {k: v.to(dtype) for k, v in proj.items()})
+        return ll.item(), torch.autograd.grad(ll, [p])[0].item()
+
+    (l64, g64), (l32, g32) = run_oracle(torch.float64), run_oracle(torch.float32)
+    assert abs(loss.item() - l64) <= 1e-4 * abs(l64) + 1e-5
+    assert abs(gp - g64) <= max(1e-4, 4 * abs(g32 - g64) / abs(g64)) * abs(g64), (gp, g64, g32)

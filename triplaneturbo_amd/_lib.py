@@ -221,6 +221,7 @@ TT_R_BWD_SOLO = 8
 TT_R_BWD_PAIR = 16
 TT_R_SPLIT2 = 32
 TT_R_SPLIT3 = 64
+TT_R_VOLSDF = 128
 TT_Q_NORMAL = 1
 TT_Q_TEX = 2
 TT_Q_EXACT_F32 = 4
@@ -257,6 +258,7 @@ def r_flag(name: str) -> int:
 def q_flag(name: str) -> int:
     return _PRECISION_FLAGS[name][1]
 PLACEMENTS = {"tt": 0, "center": 1}  # enum tt_sample_placement
+TT_PLACE_VOLSDF = 0x100  # OR-ed into the placement of tt_sample_importance: VolSDF proposal density
 
 
 def load() -> ctypes.CDLL:

@@ -7,6 +7,7 @@ struct AlphaTerms {
     float alpha, rat, den, sA, sB, half, dic_dcos;
     float pass;
     float prev_sdf, next_sdf;  // the estimated sdf at the ends of the interval (d/d inv_std needs them)
+    float d_sdf, d_k;          // use_volsdf only: d alpha / d sdf, d alpha / d inv_std
 };
 
 // 1 / x for finite, non-zero x: the hardware reciprocal (1 ulp) + one Newton step = within ~0.5 ulp of the IEEE quotient
@@ -63,3 +64,38 @@ __device__ __forceinline__ AlphaTerms neus_alpha_terms(float sdf, float cosv, fl
     return a;
 }
 
+
+// exp(-x) for x >= 0 on the hardware exp2 with the argument carried as a pair, as in sigmoid_ (~2 ulp)
+__device__ __forceinline__ float exp_neg_(float x) {
+    const float c_hi = -1.44269504f, c_lo = -1.92596303e-8f;  // -log2(e) = c_hi + c_lo
+    const float t_hi = x * c_hi;
+    const float t_lo = fmaf(x, c_hi, -t_hi) + x * c_lo;
+    const float e = __builtin_amdgcn_exp2f(t_hi);
+    return fmaf(e, t_lo * 0.693147181f, e);
+}
+
+// VolSDF density (neus_volume_renderer.py:19-23): k (0.5 + 0.5 sign(sdf) expm1(-|sdf| k)), k = clamp(inv_std, 0, 80)
+//   sdf > 0: k E / 2,  sdf < 0: k (1 - E / 2),  sdf = 0: k / 2      with E = exp(-|sdf| k)
+// `E` / `k` return exp(-|sdf| k) and the clamped k for the derivatives.
+__device__ __forceinline__ float volsdf_density(float sdf, float kstd, float& E, float& k) {
+    k = fminf(fmaxf(kstd, 0.f), 80.f);
+    E = exp_neg_(fabsf(sdf) * k);
+    return k * (sdf > 0.f ? 0.5f * E : 1.f - 0.5f * E);  // (sdf = 0: E = 1, both arms give k / 2)
+}
+
+// use_volsdf = True (neus_volume_renderer.py:95-96): alpha = |dists| x density, no clip, no normal / cosine term.
+//   d alpha / d sdf     = -|dt| k^2 E / 2         (autograd's sign(0) = 0, |.|'(0) = 0: zero at sdf = 0)
+//   d alpha / d inv_std = |dt| (density / k - sign(sdf) |sdf| k E / 2) inside the clamp [0, 80], 0 outside
+__device__ __forceinline__ AlphaTerms volsdf_alpha_terms(float sdf, float dt, float kstd) {
+    AlphaTerms a = {};
+    float E, k;
+    const float dens = volsdf_density(sdf, kstd, E, k);
+    const float adt = fabsf(dt);
+    a.alpha = adt * dens;
+    a.d_sdf = sdf != 0.f ? -0.5f * adt * k * k * E : 0.f;
+    const float shape = sdf > 0.f ? 0.5f * E : 1.f - 0.5f * E;  // density / k
+    const float dshape = (sdf > 0.f ? -0.5f : sdf < 0.f ? 0.5f : 0.f) * fabsf(sdf) * k * E;
+    a.d_k = (kstd >= 0.f && kstd <= 80.f) ? adt * (shape + dshape) : 0.f;
+    a.pass = 1.f;
+    return a;
+}

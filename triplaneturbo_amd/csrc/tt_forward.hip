@@ -617,7 +617,8 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
             const float ux = gx * ign, uy = gy * ign, uz = gz * ign;
             const float cosv = dx * ux + dy * uy + dz * uz;
             // (select, not a product: a dead lane's alpha may be NaN -- it decodes nothing)
-            float alpha = neus_alpha_terms(sdf, cosv, te - ts, kstd, cfg.cos_anneal_ratio).alpha;
+            float alpha = (cfg.flags & TT_R_VOLSDF) ? volsdf_alpha_terms(sdf, te - ts, kstd).alpha
+                                                    : neus_alpha_terms(sdf, cosv, te - ts, kstd, cfg.cos_anneal_ratio).alpha;
             if (!live) alpha = 0.f;
             const float wgt = alpha * T;
             T *= 1.f - alpha;

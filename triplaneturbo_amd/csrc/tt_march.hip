@@ -26,6 +26,7 @@ struct MarchFwdParams {
     long long n_rays;
     int S;
     float inv_std, ratio;
+    int volsdf;                // TT_R_VOLSDF: alpha = |dt| x VolSDF density (tt_alpha.h)
     const float* inv_std_dev;  // device scalar overriding inv_std (trainable variance), or null
     float* opacity;
     float* depth;
@@ -125,7 +126,8 @@ __device__ __forceinline__ void march_pass_fwd(const MarchFwdParams& p, float ks
     const float ign = rcp_(gn);
     const float nx = v.gx * ign, ny = v.gy * ign, nz = v.gz * ign;
     const float cosv = dx * nx + dy * ny + dz * nz;
-    float alpha = neus_alpha_terms(v.sdf, cosv, v.te - v.ts, kstd, p.ratio).alpha;
+    float alpha = p.volsdf ? volsdf_alpha_terms(v.sdf, v.te - v.ts, kstd).alpha
+                           : neus_alpha_terms(v.sdf, cosv, v.te - v.ts, kstd, p.ratio).alpha;
     if (!valid) alpha = 0.f;
     float total;
     Ti = a.T * wave_excl_prod(1.f - alpha, total);
@@ -251,6 +253,7 @@ struct MarchBwdParams {
     long long n_rays;
     int S;
     float inv_std, ratio;
+    int volsdf;                // TT_R_VOLSDF: alpha = |dt| x VolSDF density (tt_alpha.h)
     const float* inv_std_dev;  // device scalar overriding inv_std (trainable variance), or null
     float* g_inv_std_rays;     // (n_rays) d loss / d inv_std per ray, or null
     float* ws;  // (n_rays*S, 4): d/d sdf, d/d sdf_grad xyz
@@ -290,7 +293,8 @@ __device__ __forceinline__ f32x4 march_pass_bwd(const MarchBwdParams& p, float k
     const float ign = rcp_(gn);
     const float nx = v.gx * ign, ny = v.gy * ign, nz = v.gz * ign;
     const float cosv = rb.dx * nx + rb.dy * ny + rb.dz * nz;
-    const AlphaTerms a = neus_alpha_terms(v.sdf, cosv, v.te - v.ts, kstd, p.ratio);
+    const AlphaTerms a = p.volsdf ? volsdf_alpha_terms(v.sdf, v.te - v.ts, kstd)
+                                  : neus_alpha_terms(v.sdf, cosv, v.te - v.ts, kstd, p.ratio);
     const float alpha = valid ? a.alpha : 0.f;
     const float Ti = valid ? v.trans : 0.f;
     const float wgt = alpha * Ti;
@@ -307,14 +311,21 @@ __device__ __forceinline__ f32x4 march_pass_bwd(const MarchBwdParams& p, float k
     const float Rnext = wave_affine_prev(1.f - alpha, V * alpha, Rcarry);
     const float dalpha = Ti * (V - Rnext);
     const float drat = dalpha * a.pass * (valid ? 1.f : 0.f);
-    const float iden = rcp_(a.den);
-    const float dnum = drat * iden, dden = -drat * a.rat * iden;
-    const float dargA = (dnum + dden) * a.sA * (1.f - a.sA), dargB = (-dnum) * a.sB * (1.f - a.sB);
-    const float dA = dargA * kstd, dB = dargB * kstd;
-    // d loss / d inv_std of this sample: both logistic arguments are (estimated sdf) * inv_std  (neus...:108-109)
-    dk += dargA * a.prev_sdf + dargB * a.next_sdf;
-    const float sbar = dA + dB;
-    const float dcos = a.half * (dB - dA) * a.dic_dcos;
+    float sbar, dcos;
+    if (p.volsdf) {  // (wave-uniform) alpha depends on the sdf and inv_std only
+        sbar = drat * a.d_sdf;
+        dcos = 0.f;
+        dk += drat * a.d_k;
+    } else {
+        const float iden = rcp_(a.den);
+        const float dnum = drat * iden, dden = -drat * a.rat * iden;
+        const float dargA = (dnum + dden) * a.sA * (1.f - a.sA), dargB = (-dnum) * a.sB * (1.f - a.sB);
+        const float dA = dargA * kstd, dB = dargB * kstd;
+        // d loss / d inv_std of this sample: both logistic arguments are (estimated sdf) * inv_std  (neus...:108-109)
+        dk += dargA * a.prev_sdf + dargB * a.next_sdf;
+        sbar = dA + dB;
+        dcos = a.half * (dB - dA) * a.dic_dcos;
+    }
     const float nbx = wgt * rb.b_nx + dcos * rb.dx, nby = wgt * rb.b_ny + dcos * rb.dy,
                 nbz = wgt * rb.b_nz + dcos * rb.dz;
     float gbx, gby, gbz;
@@ -410,6 +421,7 @@ int tt_launch_march_fwd(const float* rays_d, const float* t_starts, const float*
     p.S = cfg->n_samples;
     p.inv_std = cfg->inv_std;
     p.inv_std_dev = cfg->inv_std_dev;
+    p.volsdf = (cfg->flags & TT_R_VOLSDF) ? 1 : 0;
     p.ratio = cfg->cos_anneal_ratio;
     p.opacity = opacity;
     p.depth = depth;
@@ -458,6 +470,7 @@ int tt_launch_march_bwd(const float* rays_d, const float* t_starts, const float*
     p.S = cfg->n_samples;
     p.inv_std = cfg->inv_std;
     p.inv_std_dev = cfg->inv_std_dev;
+    p.volsdf = (cfg->flags & TT_R_VOLSDF) ? 1 : 0;
     p.g_inv_std_rays = g_inv_std_rays;
     p.ratio = cfg->cos_anneal_ratio;
     p.ws = ws;

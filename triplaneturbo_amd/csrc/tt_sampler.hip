@@ -14,6 +14,7 @@
 //   binary search each) instead of a sort of K + F + 2 values.
 #include "tt_device.h"
 #include "tt_host.h"
+#include "tt_alpha.h"
 
 #pragma clang fp contract(off)  // replay the torch op order of the contract (s*far + (1-s)*near etc.)
 
@@ -85,10 +86,16 @@ __global__ __launch_bounds__(256) void k_sample_importance(ImportanceParams p) {
         const bool valid = k < K;
         const long long i = ray * K + (valid ? k : 0);
         const float ts = p.ts[i], te = p.te[i], sdf = p.sdf[i];
-        const float prev = sigmoidf_((sdf + p.step * 0.5f) * kstd);
-        const float next = sigmoidf_((sdf - p.step * 0.5f) * kstd);
-        const float alpha = fminf(fmaxf((prev - next + 1e-5f) / (prev + 1e-5f), 0.f), 1.f);
-        const float sd = valid ? (alpha / p.step) * (te - ts) : 0.f;
+        float sigma;
+        if (p.placement & TT_PLACE_VOLSDF) {  // renderer :286-287
+            float E, kc;
+            sigma = volsdf_density(sdf, kstd, E, kc);
+        } else {  // :288-297
+            const float prev = sigmoidf_((sdf + p.step * 0.5f) * kstd);
+            const float next = sigmoidf_((sdf - p.step * 0.5f) * kstd);
+            sigma = fminf(fmaxf((prev - next + 1e-5f) / (prev + 1e-5f), 0.f), 1.f) / p.step;
+        }
+        const float sd = valid ? sigma * (te - ts) : 0.f;
         float inc = sd;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void k_sample_importance(ImportanceParams p) {
     // ---- fine edges: inverse CDF at u_j ----
     for (int j = lane; j <= F; j += 64) {
         float u;
-        if (p.placement == TT_PLACE_CENTER) {
+        if ((p.placement & ~TT_PLACE_VOLSDF) == TT_PLACE_CENTER) {
             u = center_u(j, F, p.u ? p.u + ray * (F + 1) + j : nullptr);
         } else {
             u = linspace01(j, F);
@@ -186,7 +193,8 @@ extern "C" int tt_sample_importance(const float* t_starts, const float* t_ends, 
                                     float* out_t_starts, float* out_t_ends, void* stream) {
     if (!t_starts || !t_ends || !sdf || !out_t_starts || !out_t_ends || n_rays <= 0 || n_proposal <= 0 || n_fine <= 0)
         return TT_ERR_BAD_ARG;
-    if (placement != TT_PLACE_TT && placement != TT_PLACE_CENTER) return TT_ERR_BAD_ARG;
+    const int32_t place = placement & ~TT_PLACE_VOLSDF;
+    if (place != TT_PLACE_TT && place != TT_PLACE_CENTER) return TT_ERR_BAD_ARG;
     if ((!inv_std_dev && !(inv_std > 0.f)) || !(render_step_size > 0.f)) return TT_ERR_BAD_ARG;
     const size_t lds = 4u * (2u * (n_proposal + 1) + (n_fine + 1)) * sizeof(float);
     if (lds > 64u * 1024u) return TT_ERR_UNSUPPORTED;

@@ -115,6 +115,8 @@ class RenderConfig:
     exact_f32: bool = False
     wgrad_f32: bool = False  # TT_R_WGRAD_F32: tuning build only (the product library rejects it)
     bwd_pair: bool = False  # TT_R_BWD_PAIR: tuning build only (the product library rejects it)
+    # TT_R_VOLSDF: alpha = |dists| x VolSDF density instead of the NeuS alpha (neus_volume_renderer.py:19-23,:95-96)
+    use_volsdf: bool = False
 
     @property
     def prec(self) -> str:
@@ -379,7 +381,8 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
     return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
                           inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
                           (_lib.TT_R_PER_SAMPLE if per_sample else 0) | _lib.r_flag(rc.prec) |
-                          (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0) | (_lib.TT_R_BWD_PAIR if rc.bwd_pair else 0),
+                          (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0) | (_lib.TT_R_BWD_PAIR if rc.bwd_pair else 0) |
+                          (_lib.TT_R_VOLSDF if rc.use_volsdf else 0),
                           image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0, int(rc.tile_sb),
                           max(1, int(rc.grad_copies)), max(0, int(rc.tile_chunk)), max(0.0, float(rc.skip_eps_tex)),
                           max(0.0, float(rc.skip_eps_geo)), inv_std_dev, stats)
@@ -482,11 +485,12 @@ def sample_uniform(n_rays: int, n_samples: int, near: float, far: float, device,
 @torch.no_grad()
 def sample_importance(t_starts: Tensor, t_ends: Tensor, sdf: Tensor, n_fine: int, inv_std: float,
                       render_step_size: float, u_jitter: Optional[Tensor] = None, placement: str = "tt",
-                      inv_std_t: Optional[Tensor] = None):
+                      inv_std_t: Optional[Tensor] = None, use_volsdf: bool = False):
     """tt_sample_importance: proposal intervals (n_rays, K) + sdf at their mid-points -> (n_rays, K + n_fine + 1)
     intervals (proposal edges merged with n_fine + 1 inverse-CDF edges placed per `placement`).  inv_std_t: a 0-dim
-    CUDA tensor that replaces the host float (trainable variance)."""
-    place = _placement(placement)
+    CUDA tensor that replaces the host float (trainable variance).  use_volsdf: the proposal density is the VolSDF
+    density (renderer :286-287) instead of the fixed-step NeuS density (:288-297)."""
+    place = _placement(placement) | (_lib.TT_PLACE_VOLSDF if use_volsdf else 0)
     if inv_std_t is not None:
         inv_std_t = _chk(inv_std_t.detach(), "inv_std_t")
     t_starts, t_ends, sdf = _chk(t_starts, "t_starts"), _chk(t_ends, "t_ends"), _chk(sdf, "sdf")
@@ -523,7 +527,8 @@ def march_forward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, sdf: Ten
     inv_std, inv_std_dev = _inv_std_args(rc)
     cfg = _lib.RenderCfg(n_prompts=1, views_per_prompt=1, plane_h=1, plane_w=1, rays_per_view=n_rays, n_samples=S,
                          n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=inv_std,
-                         cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink, flags=0, image_w=0,
+                         cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink,
+                         flags=_lib.TT_R_VOLSDF if rc.use_volsdf else 0, image_w=0,
                          tile_sb=0, grad_copies=1, tile_chunk=0, inv_std_dev=inv_std_dev)
     f32 = dict(device=rays_d.device, dtype=torch.float32)
     if out is None:
@@ -552,7 +557,8 @@ def march_backward_raw(rays_d: Tensor, t_starts: Tensor, t_ends: Tensor, fwd: di
     inv_std, inv_std_dev = _inv_std_args(rc)
     cfg = _lib.RenderCfg(n_prompts=1, views_per_prompt=1, plane_h=1, plane_w=1, rays_per_view=n_rays, n_samples=S,
                          n_rays=n_rays, radius=rc.radius, sdf_bias_radius=rc.sdf_bias_radius, inv_std=inv_std,
-                         cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink, flags=0, image_w=0,
+                         cos_anneal_ratio=rc.cos_anneal_ratio, rgb_grad_shrink=rc.rgb_grad_shrink,
+                         flags=_lib.TT_R_VOLSDF if rc.use_volsdf else 0, image_w=0,
                          tile_sb=0, grad_copies=1, tile_chunk=0, inv_std_dev=inv_std_dev)
     if out is None:
         out = torch.empty((n_rays * S, 4), device=rays_d.device, dtype=torch.float32)

@@ -104,8 +104,6 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         c = self.cfg
         if c.estimator != "importance":
             raise NotImplementedError("estimator must be 'importance' (the reference raises for 'occgrid', :83-85)")
-        if c.use_volsdf:
-            raise NotImplementedError("use_volsdf=True is not part of the accelerated path (yaml :135)")
         assert c.normal_direction in ["front", "camera", "world"]
         self.geometry, self.material, self.background = geometry, material, background
         if material is not None and not isinstance(material, NoMaterial):
@@ -172,7 +170,8 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         rc = ops.RenderConfig(radius=self.cfg.radius, sdf_bias_radius=float(g.sdf_bias_params),
                               cos_anneal_ratio=float(self.cos_anneal_ratio),
                               rgb_grad_shrink=float(self.rgb_grad_shrink), skip_eps_tex=float(self.grad_skip_eps_tex),
-                              skip_eps_geo=float(self.grad_skip_eps_geo), precision=self.precision)
+                              skip_eps_geo=float(self.grad_skip_eps_geo), precision=self.precision,
+                              use_volsdf=bool(self.cfg.use_volsdf))
         if self.cfg.trainable_variance:
             # LearnedVariance.forward's value as a graph tensor on the device (renderer :29-35): the optimiser moves the
             # parameter every step, so nothing is read back to the host; rc.inv_std stays a placeholder the kernels ignore
@@ -199,7 +198,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
             sdf_fn, n_rays, self.cfg.num_samples_per_ray_importance, self.cfg.num_samples_per_ray,
             self.cfg.near_plane, self.cfg.far_plane, rc.inv_std, self.render_step_size, device=rays_o.device,
             stratified=self.randomized, generator=generator, placement=self.sampler_placement,
-            inv_std_t=rc.inv_std_t)
+            inv_std_t=rc.inv_std_t, use_volsdf=rc.use_volsdf)
 
     def forward(self, rays_o: Tensor, rays_d: Tensor, light_positions: Optional[Tensor] = None,
                 bg_color: Optional[Tensor] = None, noise: Optional[Tensor] = None,

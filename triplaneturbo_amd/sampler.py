@@ -39,12 +39,12 @@ def uniform_intervals(n_rays: int, n_samples: int, near: float, far: float, devi
 def importance_sampling(sdf_fn: Callable[[Tensor, Tensor], Tensor], n_rays: int, n_prop: int, n_fine: int,
                         near: float, far: float, inv_std: float, render_step_size: float, device=None,
                         stratified: bool = False, generator: Optional[torch.Generator] = None,
-                        placement: str = "tt", inv_std_t: Optional[Tensor] = None):
+                        placement: str = "tt", inv_std_t: Optional[Tensor] = None, use_volsdf: bool = False):
     """sdf_fn(t_starts, t_ends) -> sdf (n_rays, n_prop) at interval mid-points.  Returns t_starts, t_ends
     (n_rays, n_prop + n_fine + 1).  placement: "tt" | "center" (module docstring).  inv_std_t: device scalar that
-    replaces the host float `inv_std` (trainable variance)."""
+    replaces the host float `inv_std` (trainable variance).  use_volsdf: VolSDF proposal density (renderer :286-287)."""
     device = torch.device("cuda" if device is None else device)
     ts, te = uniform_intervals(n_rays, n_prop, near, far, device, stratified, generator, placement)
     u = torch.rand(n_rays, n_fine + 1, device=device, generator=generator) if stratified else None
     return ops.sample_importance(ts, te, sdf_fn(ts, te), n_fine, inv_std, render_step_size, u, placement=placement,
-                                 inv_std_t=inv_std_t)
+                                 inv_std_t=inv_std_t, use_volsdf=use_volsdf)
