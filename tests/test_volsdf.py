@@ -246,6 +246,15 @@ def test_renderer_module_accepts_use_volsdf_and_trains_the_variance():
     loss = O.synthetic_loss(out, {k: v.to(dev) for k, v in proj.items()})
     loss.backward()
     gp = r.variance._inv_std.grad.item()
+    # the fused no-grad eval render (tt_render_eval) takes the same branch: equal to the training forward on the same samples
+    r.eval()
+    r.eval_termination_eps = 1e-12  # opt-in switch that selects tt_render_eval; at 1e-12 nothing measurable is skipped
+    with torch.no_grad():
+        oe = r(ro.to(dev), rd.to(dev), None, torch.ones(3, device=dev), t_starts=ts.to(dev), t_ends=te.to(dev), **kw)
+    r.eval_termination_eps = 0.0
+    r.train()
+    for key in ("comp_rgb", "opacity", "depth", "comp_normal"):
+        assert (oe[key] - out[key].detach()).abs().max().item() <= 2e-5, key
     sw, fw = g.mlp_weights()
     sw, fw = [w.detach().cpu() for w in sw], [w.detach().cpu() for w in fw]
 
