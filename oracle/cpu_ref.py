@@ -80,6 +80,10 @@ Tensor = torch.Tensor
 #   * the correctly rounded logistic (as level 1);  F.normalize as x / sqrt(|x|^2) with |x|^2 = x^2 + (y^2 + z^2);
 #   * the sample position o + d t with ONE rounding (evaluated in fp64 and rounded: what a fused multiply-add gives) instead
 #     of a rounded product followed by a rounded sum -- the sample coordinates are where fp32 rounding enters the geometry side.
+#   alt_order(2) and (3) also
+#   * render_weight_from_alpha: the transmittance as the step-by-step recurrence T_{i+1} = T_i (1 - alpha_i) instead of
+#     torch.cumprod -- same forward values; autograd's backward is then the reverse recurrence, where cumprod's backward
+#     divides by (1 - alpha_i) and loses digits when an alpha sits next to 1 (use_volsdf: alpha is not clipped).
 # Same operations, same operands, same dtype: the pairwise distances of the three fp32 evaluations are the order /
 # implementation sensitivity of the fp32 math itself on that scene, and tests/parity.py asks of the HIP path
 #     |hip - fp32| <= max(1e-4, 1.5 x the largest of those distances).
@@ -389,6 +393,16 @@ def render_weight_from_alpha(alpha: Tensor) -> Tuple[Tensor, Tensor]:
     trans_i = prod_{j<i}(1-alpha_j), w_i = alpha_i * trans_i.  [parity unpinned]
     """
     one_minus = 1.0 - alpha
+    if _ALT_ORDER >= 2:
+        # alternative evaluations 2 / 3: the recurrence T_0 = 1, T_{i+1} = T_i (1 - alpha_i) step by step.  Same forward
+        # values; autograd's backward is then the reverse recurrence itself, where torch.cumprod's backward forms
+        # reverse_cumsum(grad * out) / input -- a division by (1 - alpha_i) that loses digits when an alpha sits next to 1
+        # (use_volsdf: alpha is not clipped and crosses 1 continuously; NeuS alpha saturates AT 1, which cumprod treats apart)
+        cols = [torch.ones_like(alpha[:, 0])]
+        for i in range(alpha.shape[1] - 1):
+            cols.append(cols[-1] * one_minus[:, i])
+        trans = torch.stack(cols, dim=1)
+        return alpha * trans, trans
     trans = torch.cumprod(
         torch.cat([torch.ones_like(alpha[:, :1]), one_minus[:, :-1]], dim=1), dim=1)
     return alpha * trans, trans

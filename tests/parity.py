@@ -121,7 +121,7 @@ def check_grads(case, g_hip, g32, g64, names=NAMES, tol32=TOL_VS_FP32, tol64=1e-
     return rows
 
 
-def kink_free_rays(cache, sdf_weights, feat_weights, ro, rd, ts, te, n_view, tau=KINK_TAU):
+def kink_free_rays(cache, sdf_weights, feat_weights, ro, rd, ts, te, n_view, tau=KINK_TAU, net="sdf"):
     """Rays none of whose samples sits on a ReLU kink of the sdf network.  The normal n = d sdf / d x of a ReLU network
     jumps by a finite amount where a hidden pre-activation crosses zero; a sample whose (fp64) pre-activation is within
     rounding distance of zero -- |h| < tau * sum_k |w_k x_k|, tau = 2^-19 = 8x the 2^-22 of a split-fp16 product, 32x fp32's
@@ -136,9 +136,9 @@ def kink_free_rays(cache, sdf_weights, feat_weights, ro, rd, ts, te, n_view, tau
         pts = (ro.reshape(-1, 1, 3).double() + rd.reshape(-1, 1, 3).double() * tm[..., None]).reshape(B, -1, 3)
         og = O.geometry_forward(pts, cache.double().repeat_interleave(n_view, 0), [w.double() for w in sdf_weights],
                                 [w.double() for w in feat_weights], output_normal=False)
-        x = og["enc_geo"]
+        x = og["enc_geo" if net == "sdf" else "enc_tex"]  # (net="feature": the same test on the feature network)
         near = torch.zeros(x.shape[0], dtype=torch.bool)
-        for w in sdf_weights[:-1]:
+        for w in (sdf_weights if net == "sdf" else feat_weights)[:-1]:
             w = w.double()
             h, scale = x @ w.T, x.abs() @ w.abs().T
             near |= ((h.abs() < tau * scale) & (scale > 0)).any(dim=1)
