@@ -585,6 +585,15 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
     do {               \
     } while (0)
 #endif
+#ifdef TT_SCATTER_DIRECT  // dev A/B (tools/build_variants.py): every reference straight to global memory, no slots
+    for (int pl = 0; pl < 3; ++pl) {
+        prep(pl, rc);
+        sc.w0 = sc.w1 = sc.m0 = sc.m1 = false;
+        sc.l0 = sc.l1 = true;
+        scatter_lost(rc, sc, Qs, Ls, grsrc, i, hi);
+    }
+    return;
+#endif
     prep(0, rc);
     sc = scatter_claim<EXACT>(rc, M, tags, dummy, i, st);
     scatter_lost(rc, sc, Qs, Ls, grsrc, i, hi);
