@@ -35,6 +35,14 @@ if os.environ.get("TT_SB_GLOBAL"):
     r.tile_sb_global = int(os.environ["TT_SB_GLOBAL"])
 if os.environ.get("TT_SB_PATCH"):
     r.tile_sb_patch = int(os.environ["TT_SB_PATCH"])
+if os.environ.get("TT_GRAD_COPIES"):  # privatised plane-gradient copies (copy = workgroup id % copies: 8 = one per XCD)
+    for m in r.modules():
+        if hasattr(m, "_render_config"):
+            def _rc(orig=m._render_config):
+                rc = orig()
+                rc.grad_copies = int(os.environ["TT_GRAD_COPIES"])
+                return rc
+            m._render_config = _rc
 gen = torch.Generator().manual_seed(1)
 cache = (torch.randn(P, 6, 32, 256, 256, generator=gen) * 0.5).to(dev).requires_grad_(True)
 ro, rd, c2w, cd = synthetic.make_cameras(P * NV, 128, 128)
