@@ -4,9 +4,14 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import triplaneturbo_amd as tt
 
+from triplaneturbo_amd import _lib
+if os.environ.get("TT_LIB_VARIANT"):  # dev A/B of an experiment build (tools/build_variants.py)
+    _lib.use_variant(os.environ["TT_LIB_VARIANT"])
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 g = tt.find("few-step-triplane-dual-stable-diffusion")({"isosurface_deformable_grid": True}).to(dev)
+if os.environ.get("TT_PRECISION"):
+    g.precision = os.environ["TT_PRECISION"]
 cache = (torch.randn(1, 6, 32, 256, 256) * 0.5).to(dev)
 lin = torch.linspace(-1.0, 1.0, 160, device=dev)
 grid = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(1, -1, 3)

@@ -357,10 +357,20 @@ struct QueryFieldParams {
     float* out_def;
 };
 
+// Two waves per SIMD in every mode: two 4-wave workgroups per CU (81 KB each), or -- PREC_S3, whose third-term images
+// bring the weights to 83 KB -- ONE 8-wave workgroup sharing one set of images (136 KB).  (Round 5: the S3 instantiation ran
+// one 4-wave workgroup per CU until the kernel-resource table showed its occupancy of 1.)
 template <int PREC>
-// (two 4-wave workgroups per CU: 81 KB each; one under PREC_S3: 110 KB)
-__global__ __launch_bounds__(256, PREC == PREC_S3 ? 1 : 2) void k_query_field(QueryFieldParams p) {
-    __shared__ __attribute__((aligned(16))) float L[FieldWFloats<PREC>::value + 4 * GC_SCRATCH_FLOATS];
+struct QueryFieldWaves {
+#ifdef TT_QF_WAVES4  // dev A/B: the one-workgroup-of-four form of PREC_S3
+    static constexpr int value = 4;
+#else
+    static constexpr int value = PREC == PREC_S3 ? 8 : 4;
+#endif
+};
+template <int PREC>
+__global__ __launch_bounds__(64 * QueryFieldWaves<PREC>::value, PREC == PREC_S3 ? 1 : 2) void k_query_field(QueryFieldParams p) {
+    __shared__ __attribute__((aligned(16))) float L[FieldWFloats<PREC>::value + QueryFieldWaves<PREC>::value * GC_SCRATCH_FLOATS];
     float* T = L + FieldWFloats<PREC>::value + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
     {  // split-fp16 images (tt_mfma16.h), same footprint as the fp32 ones
         MlpPtrs w = p.w;
@@ -1007,13 +1017,14 @@ extern "C" int tt_query_field(const float* packed, const tt_mlp_weights* w, cons
     int cus = tt_num_cus();
     if (cus <= 0) return TT_ERR_DEVICE;
     long long n_tiles = ((n_points + TT_TILE - 1) / TT_TILE) * n_batch;
-    long long blocks = (n_tiles + 3) / 4;
-    if (blocks > 2LL * cus) blocks = 2LL * cus;
     const int prec = tt_prec_of_q(flags);
+    const int waves = prec == PREC_S3 ? QueryFieldWaves<PREC_S3>::value : 4;  // per workgroup; 8 waves per CU either way
+    long long blocks = (n_tiles + waves - 1) / waves;
+    if (blocks > (8LL / waves) * cus) blocks = (8LL / waves) * cus;
     if (prec == PREC_F32)
         hipLaunchKernelGGL(k_query_field<PREC_F32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     else if (prec == PREC_S3)
-        hipLaunchKernelGGL(k_query_field<PREC_S3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_query_field<PREC_S3>, dim3((unsigned)blocks), dim3(64 * waves), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(k_query_field<PREC_S2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return tt_check_launch();

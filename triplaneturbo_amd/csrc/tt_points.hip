@@ -55,8 +55,18 @@ __device__ __forceinline__ float dot16_pair(const f32x4 (&t)[4], const float* v)
     return s + __shfl_xor(s, 32);
 }
 
+// One workgroup per CU holds the weight images; eight waves share them in the split modes (two waves per SIMD: <= 256
+// registers each), four in the fp32-MFMA mode (282 registers).
 template <int PREC>
-__global__ __launch_bounds__(256, 1) void k_points_bwd_x(PointsBwdXParams p) {
+struct PointsBwdXWaves {
+#ifdef TT_PX_WAVES4  // dev A/B: four waves in every mode (rounds 3-4)
+    static constexpr int value = 4;
+#else
+    static constexpr int value = PREC == PREC_F32 ? 4 : 8;
+#endif
+};
+template <int PREC>
+__global__ __launch_bounds__(64 * PointsBwdXWaves<PREC>::value, 1) void k_points_bwd_x(PointsBwdXParams p) {
     __shared__ __attribute__((aligned(16))) float L[PREC == PREC_S3 ? PX3_FLOATS : PX_FLOATS];
     {
         const MlpPtrs w = p.w;
@@ -241,15 +251,16 @@ extern "C" int tt_points_bwd_x(const float* packed, const tt_mlp_weights* w, con
     const int cus = tt_num_cus();
     if (cus <= 0) return TT_ERR_DEVICE;
     const long long n_tiles = ((n_points + TT_TILE - 1) / TT_TILE) * n_batch;
-    long long blocks = (n_tiles + 3) / 4;
-    if (blocks > cus) blocks = cus;
     if (!tt_qflags_ok(flags)) return TT_ERR_BAD_ARG;
     const int prec = tt_prec_of_q(flags);
+    const int waves = prec == PREC_F32 ? PointsBwdXWaves<PREC_F32>::value : PointsBwdXWaves<PREC_S3>::value;
+    long long blocks = (n_tiles + waves - 1) / waves;
+    if (blocks > cus) blocks = cus;
     if (prec == PREC_F32)
-        hipLaunchKernelGGL(k_points_bwd_x<PREC_F32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_points_bwd_x<PREC_F32>, dim3((unsigned)blocks), dim3(64 * waves), 0, (hipStream_t)stream, p);
     else if (prec == PREC_S3)
-        hipLaunchKernelGGL(k_points_bwd_x<PREC_S3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_points_bwd_x<PREC_S3>, dim3((unsigned)blocks), dim3(64 * waves), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(k_points_bwd_x<PREC_S2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_points_bwd_x<PREC_S2>, dim3((unsigned)blocks), dim3(64 * waves), 0, (hipStream_t)stream, p);
     return tt_check_launch();
 }
