@@ -24,8 +24,9 @@ for name, P, NV, Hh, Ww, S, sb in (("configs[1] 256x256 rays x 128", 1, 1, 256, 
     ro, rd, _, _ = synthetic.make_cameras(P * NV, Hh, Ww)
     ts, te = synthetic.uniform_intervals(P * NV * Hh * Ww, S, 0.1, 4.0)
     ro, rd, ts, te = ro.reshape(-1, 3).to(dev), rd.reshape(-1, 3).to(dev), ts.to(dev), te.to(dev)
-    for prec in ("split3", "f32", "split2"):
-        rc = ops.RenderConfig(precision=prec, tile_sb=sb)
+    chunks = [int(c) for c in os.environ.get("TT_CHUNKS", "0").split(",")]  # samples per work item (0 = automatic)
+    for prec, chunk in [(pr, c) for pr in os.environ.get("TT_PRECISIONS", "split3,f32,split2").split(",") for c in chunks]:
+        rc = ops.RenderConfig(precision=prec, tile_sb=sb, tile_chunk=chunk)
         run = lambda: ops.decode_rays(packed[:P], sw, None, ro, rd, ts, te, Hh * Ww, rc, need_normal=False, need_features=False, image_w=Ww)  # noqa: E731
         sdf = run()[0]
         torch.cuda.synchronize()
@@ -35,4 +36,4 @@ for name, P, NV, Hh, Ww, S, sb in (("configs[1] 256x256 rays x 128", 1, 1, 256, 
             run()
         b.record()
         torch.cuda.synchronize()
-        print(f"{name:34s} {prec:7s} {a.elapsed_time(b) / 50:.4f} ms   sha {hashlib.sha256(sdf.cpu().numpy().tobytes()).hexdigest()[:16]}")
+        print(f"{name:34s} {prec:7s} chunk {chunk:3d}  {a.elapsed_time(b) / 50:.4f} ms   sha {hashlib.sha256(sdf.cpu().numpy().tobytes()).hexdigest()[:16]}")

@@ -35,12 +35,14 @@ if os.environ.get("TT_SB_GLOBAL"):
     r.tile_sb_global = int(os.environ["TT_SB_GLOBAL"])
 if os.environ.get("TT_SB_PATCH"):
     r.tile_sb_patch = int(os.environ["TT_SB_PATCH"])
-if os.environ.get("TT_GRAD_COPIES"):  # privatised plane-gradient copies (copy = workgroup id % copies: 8 = one per XCD)
+if os.environ.get("TT_GRAD_COPIES") or os.environ.get("TT_TILE_CHUNK"):
+    # privatised plane-gradient copies (copy = workgroup id % copies: 8 = one per XCD) / samples of a ray block per work item
     for m in r.modules():
         if hasattr(m, "_render_config"):
             def _rc(orig=m._render_config):
                 rc = orig()
-                rc.grad_copies = int(os.environ["TT_GRAD_COPIES"])
+                rc.grad_copies = int(os.environ.get("TT_GRAD_COPIES", rc.grad_copies))
+                rc.tile_chunk = int(os.environ.get("TT_TILE_CHUNK", rc.tile_chunk))
                 return rc
             m._render_config = _rc
 gen = torch.Generator().manual_seed(1)

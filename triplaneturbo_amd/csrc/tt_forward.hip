@@ -272,6 +272,12 @@ __device__ __forceinline__ void stage_decode_images(float* L, const MlpPtrs& w) 
     }
 }
 
+#ifndef TT_DR_GEO_SAMPLES
+#define TT_DR_GEO_SAMPLES 64  // samples of a ray block per work item of the sdf-only decode (tt_decode_rays)
+#endif
+#ifndef TT_DR_GEO_MIN_ITEMS
+#define TT_DR_GEO_MIN_ITEMS 0  // ... and no minimum number of items per wave slot
+#endif
 // 8 waves (2 per SIMD) share one set of split-fp16 weight images (93 KB: one workgroup per CU)
 #ifndef DECODE_THREADS
 #define DECODE_THREADS 512
@@ -804,7 +810,7 @@ int tt_validate_cfg(const tt_render_cfg* cfg) {
 // Fills the tile geometry and picks the chunk length: enough items (>= 8 per wave slot) for balance, chunks as
 // long as possible so consecutive depths of the same rays reuse L1/L2-resident texels.
 long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g, int default_order,
-                       int steps_per_item) {
+                       int steps_per_item, int min_items_per_slot) {
     g->n_rays = cfg->n_rays;
     g->rays_per_view = cfg->rays_per_view;
     g->n_samples = cfg->n_samples;
@@ -840,7 +846,7 @@ long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom*
     // dynamic queue: per-item ray setup + one pop amortised, items fine enough that the last ones finish together -- but
     // at least 8 items per wave slot
     int n_chunks = (n_steps + steps_per_item - 1) / steps_per_item;
-    const int min_chunks = (int)((8 * wave_slots + n_blocks - 1) / n_blocks);
+    const int min_chunks = (int)(((long long)min_items_per_slot * wave_slots + n_blocks - 1) / n_blocks);
     if (n_chunks < min_chunks) n_chunks = min_chunks;
     if (n_chunks < 1) n_chunks = 1;
     if (n_chunks > n_steps) n_chunks = n_steps;
@@ -956,7 +962,18 @@ extern "C" int tt_decode_rays(const float* packed, const tt_mlp_weights* w, cons
     p.sdf_grad = sdf_grad;
     p.features = features;
     const long long slots = (long long)cus * (DECODE_THREADS / 64);
-    p.n_items = tt_make_geom(cfg, slots, &p.geom, 1, 12);
+    // The sdf-only decode (the sampler's proposal pass) is so cheap per tile step that an item's ray set-up, its queue pop and
+    // its first-touch texel misses show: items of TT_DR_GEO_SAMPLES (64) samples and no minimum number of items per wave slot
+    // (round 5 sweep, tools/time_proposal.py / time_training_shapes.py: 256 x 256 x 128 0.837 -> 0.815 ms, the two launches of
+    // a PatchRenderer step at the training shape 0.80 -> 0.63 ms; whole-ray items are better still for large launches and
+    // worse for the 800-block patch render).
+    if (!need_n && !need_t) {
+        const int sb = cfg->tile_sb > 0 ? cfg->tile_sb : 2;
+        const int spi = (TT_DR_GEO_SAMPLES + sb - 1) / sb;
+        p.n_items = tt_make_geom(cfg, slots, &p.geom, 1, spi > 1 ? spi : 1, TT_DR_GEO_MIN_ITEMS);
+    } else {
+        p.n_items = tt_make_geom(cfg, slots, &p.geom, 1, 12);
+    }
     long long blocks = cus;
     long long need = (p.n_items + 7) / 8;
     if (blocks > need) blocks = need;

@@ -29,7 +29,7 @@ struct TileGeom;
 // three kernels once the queue is dynamic: concurrent waves of an XCD then walk ONE pixel block's depth chunks and
 // its neighbours rather than one depth slab of the whole image share).
 long long tt_make_geom(const tt_render_cfg* cfg, long long wave_slots, TileGeom* g, int default_order,
-                       int steps_per_item = 6);
+                       int steps_per_item = 6, int min_items_per_slot = 8);
 
 // Work-queue counters for one kernel launch: 8 int32 heads (one per XCD) in a library-owned device scratch, zeroed on
 // `stream` by a one-wave kernel enqueued here (so the caller must launch the kernel on the same stream, next).  A
