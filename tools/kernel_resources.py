@@ -8,8 +8,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "triplaneturbo_amd", "csrc", "*.hip")))
-extra = os.environ.get("EXTRA_FLAGS", "").split()
+sys.path.insert(0, ROOT)
+from triplaneturbo_amd._lib import SOURCE_FLAGS  # noqa: E402  (the per-file flags the product library is built with)
+# EXTRA_FLAGS="..." replaces the per-file flags (A/B of scheduler options); unset = exactly the product build's flags
+extra_env = os.environ.get("EXTRA_FLAGS")
 for f in files:
+    extra = extra_env.split() if extra_env is not None else list(SOURCE_FLAGS.get(os.path.basename(f), []))
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fno-gpu-rdc",
            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "triplaneturbo_amd", "csrc"),
            "-Rpass-analysis=kernel-resource-usage", "-c", f, "-o", "/dev/null"] + extra
