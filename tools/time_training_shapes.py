@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import triplaneturbo_amd as tt  # noqa: E402
 from triplaneturbo_amd import _lib, ops, synthetic  # noqa: E402
 
+if os.environ.get("TT_TUNING_BUILD"):  # the -DTT_TUNING library: honours TT_DEBUG_FLAGS (ablations)
+    _lib.use_tuning_build()
 if os.environ.get("TT_LIB_VARIANT"):  # dev A/B of an experiment build (tools/build_variants.py)
     _lib.use_variant(os.environ["TT_LIB_VARIANT"])
 
