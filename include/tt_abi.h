@@ -172,8 +172,8 @@ typedef struct {
                              weight-gradient outer products on the fp32-input MFMA instead of split-fp16 products with
                              per-launch operand scales; the round-2 A/B switch, TT_R_SPLIT2 only */
 #define TT_R_BWD_SOLO 8   /* backward: force the one-wave-per-tile decode kernels (the default) */
-#define TT_R_BWD_PAIR 16  /* TUNING BUILD ONLY (the product library returns TT_ERR_UNSUPPORTED): the experimental wave-pair
-                             texture kernel of round 4 (csrc/tt_backward_tex2.hip), TT_R_SPLIT2 only */
+#define TT_R_BWD_PAIR 16  /* RESERVED, always TT_ERR_UNSUPPORTED: selected the experimental wave-pair texture kernel of round 4
+                             (two waves per SIMD; correct and 1.4x slower; removed from the tree in round 6) */
 
 /* tt_query_points / tt_query_field / tt_decode_rays / tt_points_bwd_* flags */
 #define TT_Q_NORMAL 1    /* output sdf_grad (analytic normal path) */

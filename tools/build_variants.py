@@ -15,5 +15,5 @@ for spec in sys.argv[1:]:
     name, _, defs = spec.partition("=")
     flags = [d for d in defs.split(",") if d]
     # "@plain" drops the per-translation-unit flags of _lib.SOURCE_FLAGS (A/B of those flags themselves)
-    print(_lib.build(force=True, variant=name, defines=[f for f in flags if f != "@plain"],
+    print(_lib.build(force=True, variant=name, tuning=bool(os.environ.get("TT_VARIANT_TUNING")), defines=[f for f in flags if f != "@plain"],
                      source_flags=SRC.get(name, {} if "@plain" in flags else None)))

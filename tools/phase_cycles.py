@@ -9,7 +9,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from triplaneturbo_amd import _lib  # noqa: E402
 
-_lib.use_tuning_build()
+if os.environ.get("TT_LIB_VARIANT"):  # a -DTT_TUNING experiment build (tools/build_variants.py with TT_VARIANT_TUNING=1)
+    _lib.use_variant(os.environ["TT_LIB_VARIANT"])
+else:
+    _lib.use_tuning_build()
 import bench  # noqa: E402
 from triplaneturbo_amd import functional, ops  # noqa: E402
 

@@ -22,14 +22,16 @@ LIB_PATH = os.path.join(_HERE, "libtt_hip.so")
 # environment variables (profiling ablations and tuning sweeps, tools/).  The product library above never calls getenv.
 _DEFAULT_LIB_PATH = LIB_PATH
 TUNING_LIB_PATH = os.path.join(_HERE, "libtt_hip_tuning.so")
-SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_backward_tex.hip", "tt_backward_tex2.hip", "tt_points.hip", "tt_composite.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
+SOURCES = ["tt_forward.hip", "tt_march.hip", "tt_backward.hip", "tt_backward_tex.hip", "tt_points.hip", "tt_composite.hip", "tt_grad2.hip", "tt_sampler.hip", "tt_hashgrid.hip", "tt_host.cpp"]
 # per-translation-unit flags: the texture backward is faster under hipcc's max-ILP scheduling strategy (3.11 -> 3.02 ms;
 # the other kernels are not); the geometry backward is faster with its transient MFMA results in VGPRs rather than AGPRs
 # (-amdgpu-mfma-vgpr-form: 471 -> 248 v_accvgpr_read, 3.045 -> 2.995 ms; texture backward slower, forward neutral) and
 # without the scheduler's register-pressure rescheduling stage, which has nothing to win at one wave per SIMD
 # (-amdgpu-disable-unclustered-high-rp-reschedule: 2.945 -> 2.865 ms; forward slower, texture neutral):
 # profiles/experiments/README.md
-SOURCE_FLAGS = {"tt_backward_tex.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+# Round 6 (dense-rank scatter): the texture unit is now faster WITHOUT max-ILP and, like the geometry unit, without the
+# register-pressure rescheduling stage (same-box A/B, texture backward 3.36 max-ilp / 3.32 no flags / 3.30 this).
+SOURCE_FLAGS = {"tt_backward_tex.hip": ["-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"],
                 "tt_backward.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form",
                                     "-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"]}
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared", "-fno-gpu-rdc"]

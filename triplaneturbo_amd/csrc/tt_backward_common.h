@@ -8,6 +8,7 @@
 #include "tt_alpha.h"
 #include "tt_host.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -210,102 +211,6 @@ __device__ __forceinline__ void wgrad16_row(f32x16 (&acc)[NY / 32], const float*
     }
 }
 
-// ---- fragment images: activation vectors in LDS as ready-made split-fp16 MFMA fragments -------------------------------
-// A 16 n-element vector of the tile's 32 samples is stored as blocks [k-step][half-wave] of 32 rows (samples) x 8 halfs =
-// the B fragment of that sample for that k-step: one ds_write_b128 per lane and k-step straight from a Split16 (a hi image
-// and a lo image), instead of one ds_write_b32 per element into the [index][sample] scratch of rounds 2-3.  A block is
-// padded to FR_BLK halfs so that the TRANSPOSED reads below hit all 64 banks (block stride = 16 dwords mod 64, k-step
-// stride = 32).
-#define FR_BLK 288
-typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-// fragments of one k-step: (hi, lo) 8 halfs each
-struct Frag {
-    h8_t h, l;
-};
-__device__ __forceinline__ Frag frag_lds(const half_t* img_h, const half_t* img_l, int ks, int hi, int j) {
-    Frag f;
-    f.h = *reinterpret_cast<const h8_t*>(img_h + (ks * 2 + hi) * FR_BLK + j * 8);
-    f.l = *reinterpret_cast<const h8_t*>(img_l + (ks * 2 + hi) * FR_BLK + j * 8);
-    return f;
-}
-__device__ __forceinline__ void frag_store(half_t* img_h, half_t* img_l, int ks, int hi, int j, const Frag& f) {
-    *reinterpret_cast<h8_t*>(img_h + (ks * 2 + hi) * FR_BLK + j * 8) = f.h;
-    *reinterpret_cast<h8_t*>(img_l + (ks * 2 + hi) * FR_BLK + j * 8) = f.l;
-}
-// all k-steps of a split vector (this lane: sample i, half-wave hi)
-template <int N, int PAIR, int NT>
-__device__ __forceinline__ void frag_image_store(half_t* img_h, half_t* img_l, const Split16<N, PAIR, NT>& v, int i, int hi) {
-#pragma unroll
-    for (int s = 0; s < N / 16; ++s) {
-        *reinterpret_cast<u4_t*>(img_h + (s * 2 + hi) * FR_BLK + i * 8) = u4_t{v.h[4 * s], v.h[4 * s + 1], v.h[4 * s + 2], v.h[4 * s + 3]};
-        *reinterpret_cast<u4_t*>(img_l + (s * 2 + hi) * FR_BLK + i * 8) = u4_t{v.l[4 * s], v.l[4 * s + 1], v.l[4 * s + 2], v.l[4 * s + 3]};
-    }
-}
-// ---- outer-product operands straight from the fragment images: transposed LDS reads ----
-// An outer product over the samples wants, per lane = matrix row (or column), the 32 samples as k-slots; the images hold,
-// per sample, 8 elements as k-slots.  ds_read_b64_tr_b16 turns one into the other: a 16-lane group whose lane 4 j + q
-// points at the 8-byte piece q (half-wave block q & 1, upper / lower four slots q >> 1) of sample s0 + j receives, in lane
-// 4 q + e, slot e of that piece for the four samples j = 0..3.  Four reads cover this half-wave's 16 samples
-// (register 4 n + j <-> sample 16 hh' + 4 n + j); the hi and the lo image are read alike and zipped into (hi | lo << 16).
-// Which ELEMENT of the 32-element block a lane ends up with depends on the slot order of the image: identity for
-// PAIR_SEQ images, tr_elem() for PAIR_TR ones -- a permutation of the rows of the accumulated matrix, undone at the flush.
-__device__ __forceinline__ int tr_elem(int x) {  // lane x (0..31) of a PAIR_TR operand holds this element of the block
-    const int q = (x >> 2) & 3, e = x & 3;
-    return 16 * (x >> 4) + 2 * (e & 1) + 8 * (e >> 1) + (q >> 1) + 4 * (q & 1);
-}
-// ORDER 0: register 4 n + j <-> sample 16 hh' + 4 n + j (both operands of a product built this way).  ORDER 1: register
-// 4 n + j <-> sample 8 n + 4 hh' + j, the k-slot order of wg16_frag -- for products whose other operand comes from the
-// [index][sample] scratch.
-template <int ORDER = 0>
-__device__ __forceinline__ void tr_operand(const half_t* img_h, const half_t* img_l, int blk, int lane, unsigned (&T)[16]) {
-    const int L = lane & 15, gg = lane >> 4, j = L >> 2, q = L & 3;
-    const int row0 = ORDER == 0 ? 16 * (gg >> 1) + j : 4 * (gg >> 1) + j;  // the read n adds 4 n / 8 n rows
-    const int off = ((2 * blk + (gg & 1)) * 2 + (q & 1)) * FR_BLK + row0 * 8 + 4 * (q >> 1);  // halfs
-    const lds_sv4_t* ph = (const lds_sv4_t*)(img_h + off);
-    const lds_sv4_t* pl = (const lds_sv4_t*)(img_l + off);
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {  // four more samples per read: + 4 rows of 16 bytes
-        const sv4_t h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_sv4_t*>(ph) + (ORDER == 0 ? 8 : 16) * n);
-        const sv4_t l4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_sv4_t*>(pl) + (ORDER == 0 ? 8 : 16) * n);
-        const u2_t hu = __builtin_bit_cast(u2_t, h4), lu = __builtin_bit_cast(u2_t, l4);
-        T[4 * n + 0] = __builtin_amdgcn_perm(lu[0], hu[0], 0x05040100u);
-        T[4 * n + 1] = __builtin_amdgcn_perm(lu[0], hu[0], 0x07060302u);
-        T[4 * n + 2] = __builtin_amdgcn_perm(lu[1], hu[1], 0x05040100u);
-        T[4 * n + 3] = __builtin_amdgcn_perm(lu[1], hu[1], 0x07060302u);
-    }
-}
-// acc += X Y^T over the 32 samples (X, Y: tr_operand outputs)
-__device__ __forceinline__ void outer16(f32x16& acc, const unsigned (&X)[16], const unsigned (&Y)[16]) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const h8_t xa = __builtin_bit_cast(h8_t, u4_t{X[4 * g], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]});
-        const h8_t yb = __builtin_bit_cast(h8_t, u4_t{Y[4 * g], Y[4 * g + 1], Y[4 * g + 2], Y[4 * g + 3]});
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, yb, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, wg16_swap(yb), acc, 0, 0, 0);
-    }
-}
-
-
-// acc[n] += X Y_n^T: X = a tr_operand<1> (32 rows = lanes), Y_n = rows 32 n .. of the [index][sample] scratch (wg16_frag)
-template <int NY>
-__device__ __forceinline__ void wgrad16_xt(f32x16 (&acc)[NY], const unsigned (&XT)[16], const float* Ys, int i, int hi) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const h8_t xa = __builtin_bit_cast(h8_t, u4_t{XT[4 * t], XT[4 * t + 1], XT[4 * t + 2], XT[4 * t + 3]});
-        h8_t yb[NY], ys[NY];
-#pragma unroll
-        for (int n = 0; n < NY; ++n) {
-            yb[n] = wg16_frag(Ys, 32 * n + i, t, hi);
-            ys[n] = wg16_swap(yb[n]);
-        }
-#pragma unroll
-        for (int n = 0; n < NY; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, yb[n], acc[n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < NY; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, ys[n], acc[n], 0, 0, 0);
-    }
-}
-
 // workgroup-wide max of a per-thread value through a shared word (all threads call; v >= 0)
 __device__ __forceinline__ float block_max(float v, unsigned* word) {
     __syncthreads();
@@ -403,7 +308,7 @@ __device__ __forceinline__ void scatter_clear(float* M, int lane) {
     }
 }
 
-// The three planes of one tile step, software-pipelined.  Everything except the rare lost-reference path is
+// (TT_SCATTER_V1, rounds 2-5; kept for A/B builds) The three planes of one tile step, software-pipelined.  Everything except the rare lost-reference path is
 // straight-line code (no per-reference branches: inactive references CAS a per-lane dummy tag and store to a dump
 // row of M; empty slots are dropped by the buffer range check), so that plane p's 32 MFMAs (2048 matrix-pipe cycles,
 // one wave per SIMD: nothing else would fill them) run over plane p+1's corner set-up, slot claims and M fill:
@@ -416,7 +321,7 @@ __device__ __forceinline__ void scatter_clear(float* M, int lane) {
 struct PlaneRefs {  // the two corners (2hi, 2hi+1) of this lane's sample in one plane
     float c0, c1;   // coefficient (0: no reference), normalised per sample unless EXACT
     int o0, o1;     // absolute texel index (prompt and plane included)
-    int h0, h1;     // slot: 8x8 torus hash of the texel coordinates
+    int h0, h1;     // entry of the texel table: 16x16 torus hash of the texel coordinates (V1: 8x8 slot)
     float qs;       // factor the sample's row of Q must be staged with (inverse of the coefficient normalisation)
 };
 // NORM: the sample's four coefficients are scaled by the power of two that brings the largest into [2^14, 2^15) -- the
@@ -442,18 +347,20 @@ __device__ __forceinline__ PlaneRefs plane_refs(const float (&coef)[4], const in
     r.o1 = hi ? aoff[3] : aoff[1];
     r.h0 = hi ? hs[2] : hs[0];
     r.h1 = hi ? hs[3] : hs[1];
+#ifdef TT_SCATTER_V1  // the 8 x 8 window of rounds 2-5 out of the 16 x 16 hash
+    r.h0 = ((r.h0 >> 1) & 0x38) | (r.h0 & 7);
+    r.h1 = ((r.h1 >> 1) & 0x38) | (r.h1 & 7);
+#endif
     return r;
 }
-struct ClaimState {
-    bool w0, w1;  // wrote M (slot won or shared with the same texel)
-    bool m0, m1;  // won the slot: this lane resets the tag
-    bool l0, l1;  // lost the slot to a different texel: direct atomics
-};
-
 __device__ __forceinline__ void scatter_init_tags(int* tags, int lane) {
+#ifdef TT_SCATTER_V1
     tags[lane] = -1;
     tags[64 + lane] = -1;
     if (lane < 32) tags[128 + lane] = -2;  // dummies: never empty, never equal to a texel index
+#else
+    if (lane < 32) tags[lane] = -2;  // the dummy words inactive references CAS: never empty, never equal to a texel index
+#endif
 }
 
 // store / clear one coefficient of M (column i = this lane's sample; row 64 = dump row)
@@ -480,40 +387,11 @@ __device__ __forceinline__ void m_zero(float* M, int row, int i) {
     }
 }
 
-// st (tuning build): per-wave counters [0] active references, [1] lost references, [2] plane-tiles
-template <bool EXACT>
-__device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M, int* tg, int* dummy, int i,
-                                                    unsigned long long* st = nullptr) {
-    ClaimState s;
-    const bool a0 = r.c0 != 0.f, a1 = r.c1 != 0.f;
-    const int old0 = atomicCAS(a0 ? tg + r.h0 : dummy, -1, r.o0);
-    const int old1 = atomicCAS(a1 ? tg + r.h1 : dummy, -1, r.o1);
-    s.m0 = old0 == -1;
-    s.m1 = old1 == -1;
-    s.w0 = tt_eq_either(old0, -1, r.o0);  // won the slot, or it already holds this texel (one compare: tt_device.h)
-    s.w1 = tt_eq_either(old1, -1, r.o1);
-    // not written to M.  (An inactive reference CASes the dummy tag -2, so it is "not written" too; what makes a
-    // reference LOST is a non-zero coefficient on top -- scatter_lost tests the coefficient it selects with this flag,
-    // instead of combining two lane masks here.)
-    s.l0 = !s.w0;
-    s.l1 = !s.w1;
-    m_store<EXACT>(M, s.w0 ? r.h0 : 64, i, r.c0);
-    m_store<EXACT>(M, s.w1 ? r.h1 : 64, i, r.c1);
-#ifdef TT_TUNING
-    if (st) {  // wave-uniform values, flushed once per wave with the phase timers
-        st[0] += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
-        st[1] += __popcll(__ballot((s.l0 ? r.c0 : 0.f) != 0.f)) + __popcll(__ballot((s.l1 ? r.c1 : 0.f) != 0.f));
-        st[2] += 1;
-    }
-#endif
-    return s;
-}
-
-// references that lost their slot (tile footprint wider than the 8x8 window: sparse rays) go straight to global
+// references that lost their slot (tile footprint wider than the slot window / texel table: sparse rays) go straight to global
 // memory, one half-wave per reference (lanes <-> channels: a coalesced 128-byte atomic each)
-__device__ __forceinline__ void scatter_lost(const PlaneRefs& r, const ClaimState& s, const float* Qs, float* Ls,
+__device__ __forceinline__ void scatter_lost(const PlaneRefs& r, bool l0, bool l1, const float* Qs, float* Ls,
                                              __amdgpu_buffer_rsrc_t grsrc, int i, int hi) {
-    const float lc0 = s.l0 ? r.c0 : 0.f, lc1 = s.l1 ? r.c1 : 0.f;  // coefficient of a lost corner, else 0
+    const float lc0 = l0 ? r.c0 : 0.f, lc1 = l1 ? r.c1 : 0.f;  // coefficient of a lost corner, else 0
     const unsigned long long bal = __ballot(__builtin_fabsf(lc0) + __builtin_fabsf(lc1) != 0.f);
     if (bal == 0) return;
     float* Lc = Ls;                                 // [sample][4] coefficient of a lost corner, else 0
@@ -545,6 +423,42 @@ __device__ __forceinline__ void scatter_lost(const PlaneRefs& r, const ClaimStat
             }
         }
     }
+}
+
+#ifdef TT_SCATTER_V1
+struct ClaimState {
+    bool w0, w1;  // wrote M (slot won or shared with the same texel)
+    bool m0, m1;  // won the slot: this lane resets the tag
+    bool l0, l1;  // lost the slot to a different texel: direct atomics
+};
+
+// st (tuning build): per-wave counters [0] active references, [1] lost references, [2] plane-tiles
+template <bool EXACT>
+__device__ __forceinline__ ClaimState scatter_claim(const PlaneRefs& r, float* M, int* tg, int* dummy, int i,
+                                                    unsigned long long* st = nullptr) {
+    ClaimState s;
+    const bool a0 = r.c0 != 0.f, a1 = r.c1 != 0.f;
+    const int old0 = atomicCAS(a0 ? tg + r.h0 : dummy, -1, r.o0);
+    const int old1 = atomicCAS(a1 ? tg + r.h1 : dummy, -1, r.o1);
+    s.m0 = old0 == -1;
+    s.m1 = old1 == -1;
+    s.w0 = tt_eq_either(old0, -1, r.o0);  // won the slot, or it already holds this texel (one compare: tt_device.h)
+    s.w1 = tt_eq_either(old1, -1, r.o1);
+    // not written to M.  (An inactive reference CASes the dummy tag -2, so it is "not written" too; what makes a
+    // reference LOST is a non-zero coefficient on top -- scatter_lost tests the coefficient it selects with this flag,
+    // instead of combining two lane masks here.)
+    s.l0 = !s.w0;
+    s.l1 = !s.w1;
+    m_store<EXACT>(M, s.w0 ? r.h0 : 64, i, r.c0);
+    m_store<EXACT>(M, s.w1 ? r.h1 : 64, i, r.c1);
+#ifdef TT_TUNING
+    if (st) {  // wave-uniform values, flushed once per wave with the phase timers
+        st[0] += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
+        st[1] += __popcll(__ballot((s.l0 ? r.c0 : 0.f) != 0.f)) + __popcll(__ballot((s.l1 ? r.c1 : 0.f) != 0.f));
+        st[2] += 1;
+    }
+#endif
+    return s;
 }
 
 // prep(pl, refs): corner set-up of plane pl for this lane's sample (and, where Q differs per plane, its staging into
@@ -590,13 +504,13 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
         prep(pl, rc);
         sc.w0 = sc.w1 = sc.m0 = sc.m1 = false;
         sc.l0 = sc.l1 = true;
-        scatter_lost(rc, sc, Qs, Ls, grsrc, i, hi);
+        scatter_lost(rc, sc.l0, sc.l1, Qs, Ls, grsrc, i, hi);
     }
     return;
 #endif
     prep(0, rc);
     sc = scatter_claim<EXACT>(rc, M, tags, dummy, i, st);
-    scatter_lost(rc, sc, Qs, Ls, grsrc, i, hi);
+    scatter_lost(rc, sc.l0, sc.l1, Qs, Ls, grsrc, i, hi);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
         int* const tg = tags + 64 * (pl & 1);
@@ -699,13 +613,335 @@ __device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigne
         *(sc.m0 ? tg + rc.h0 : dummy) = sc.m0 ? -1 : -2;
         *(sc.m1 ? tg + rc.h1 : dummy) = sc.m1 ? -1 : -2;
         if (pl < 2) {
-            scatter_lost(rn, sn, Qs, Ls, grsrc, i, hi);
+            scatter_lost(rn, sn.l0, sn.l1, Qs, Ls, grsrc, i, hi);
             rc = rn;
             sc = sn;
         }
         TT_SUBPHASE(5);
     }
 }
+
+#else  // !TT_SCATTER_V1
+
+// =====================================================================================================================
+// Round 6: texel table -> DENSE ranks -> short flush, up to 128 distinct texels per plane-tile (two 64-row passes).
+//
+// What rounds 2-5 did (TT_SCATTER_V1 above): slot = 8 x 8 torus hash of the texel, 64 slots, every plane flushes all 64
+// slots (32 atomic instructions, the empty ones dropped by the buffer range check), references that lose their slot go
+// out one by one.  Measured / simulated in round 6 (tools/scatter_sim.py, profiles/r06_scatter_*.txt): a plane-tile of the
+// headline scene holds 25-34 DISTINCT texels (half of the 32 flush instructions carry nothing), one of the reference's
+// sparse training renders 63-73 (up to 128) -- a hash window of 64 slots keeps ~44 of them and sends 28 % of the references
+// down the one-by-one path.  Now:
+//   * claims go into a 16 x 16 torus table (256 entries; 4 % of the training shape's references collide there, 0.1 % of
+//     the headline's) -- one LDS CAS per reference as before;
+//   * the distinct texels are RANKED: the winner of an entry (exactly one reference per distinct texel) takes the next rank
+//     r < n (two ballots + mbcnt over the winner flags), copies the tag to ctag[r] and leaves r in the entry for the
+//     references that share the texel;
+//   * M row = rank.  Ranks 0..63 are combined and flushed by pass A, ranks 64..127 (n > 64: wave-uniform branch) by a
+//     second pass over the SAME 64-row M buffer and accumulators (32 samples x 4 corners = 128 references: n <= 128 always);
+//   * the flush issues 4 ceil(n / 8) atomic instructions instead of 32 (wave-uniform branches per group of 8 rows;
+//     ctag[n .. n+7] = -1 keeps the tail of the last group out of range).
+// Tags need no double buffer any more: a plane's table entries go back to empty right after they were ranked (DS
+// operations of a wave execute in order), only the compacted tags (read by the flush after the next plane's claims) alternate.
+// LDS per wave (ints, behind the lost-reference lists at Ls + 256; all inside the kernels' existing scratch):
+//   htab[256] | ctag[2][136] | cdump[64]          dummies: tags[0..31] (scatter_init_tags)
+#ifndef TT_SC2_NO_PASSB
+#define TT_SC2_NO_PASSB 0
+#endif
+#ifndef TT_SC2_FLUSH_ALL
+#define TT_SC2_FLUSH_ALL 0
+#endif
+#define SC2_HT 256
+#define SC2_CT 136
+#define SC2_INTS (SC2_HT + 2 * SC2_CT + 64)
+
+struct Sc2State {
+    int rx0, rx1;  // dense rank of the lane's two references; 255 = not in the table (inactive, or lost to another texel)
+    bool l0, l1;   // not in the table (LOST if the coefficient is non-zero: scatter_lost tests that)
+    int n;         // wave-uniform: distinct texels of this plane-tile in the table
+};
+
+// claims of one plane, ranking, compacted tags into ct[0 .. n-1] (+ 8 x -1), table back to empty.
+// The WINNER of an entry (its CAS found it empty: exactly one reference per distinct texel) takes the next rank -- two
+// ballots + mbcnt over the winner flags, no pass over the table --, leaves it in the entry (as -2 - rank: never "empty",
+// never a texel index) for the references that share the texel to read, copies the tag to ct[rank], and puts the entry
+// back to empty once everybody has read (DS operations of a wave execute in order).
+// st (tuning build): per-wave counters [0] active references, [1] lost references, [2] plane-tiles
+__device__ __forceinline__ Sc2State sc2_claim_rank(const PlaneRefs& r, int* htab, int* ct, int* cdump, int* dummy,
+                                                   int lane, unsigned long long* st = nullptr) {
+    Sc2State s;
+    const bool a0 = r.c0 != 0.f, a1 = r.c1 != 0.f;
+    int* const e0 = a0 ? htab + r.h0 : dummy;
+    int* const e1 = a1 ? htab + r.h1 : dummy;
+    const int old0 = atomicCAS(e0, -1, r.o0);
+    const int old1 = atomicCAS(e1, -1, r.o1);
+    const bool w0 = tt_eq_either(old0, -1, r.o0), w1 = tt_eq_either(old1, -1, r.o1);  // the entry holds this texel
+    s.l0 = !w0;
+    s.l1 = !w1;
+    const bool m0 = old0 == -1, m1 = old1 == -1;
+    const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1);
+    const int n0 = __popcll(b0);
+    const int r0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u));
+    const int r1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u));
+    s.n = n0 + __popcll(b1);
+    int* const x0 = m0 ? e0 : dummy;  // (a value <= -2 in a dummy word is as good as the -2 it starts with)
+    int* const x1 = m1 ? e1 : dummy;
+    *x0 = -2 - r0;
+    *x1 = -2 - r1;
+    *(m0 ? ct + r0 : cdump + lane) = r.o0;
+    *(m1 ? ct + r1 : cdump + lane) = r.o1;
+    *(lane < 8 ? ct + s.n + lane : cdump + lane) = -1;  // the tail of the last flush group: out of range, dropped
+    const int q0 = -2 - *e0, q1 = -2 - *e1;
+    *x0 = m0 ? -1 : -2;  // the table back to empty
+    *x1 = m1 ? -1 : -2;
+    s.rx0 = w0 ? q0 : 255;
+    s.rx1 = w1 ? q1 : 255;
+#ifdef TT_TUNING
+    if (st) {  // wave-uniform values, flushed once per wave with the phase timers
+        st[0] += __popcll(__ballot(a0)) + __popcll(__ballot(a1));
+        st[1] += __popcll(__ballot((s.l0 ? r.c0 : 0.f) != 0.f)) + __popcll(__ballot((s.l1 ? r.c1 : 0.f) != 0.f));
+        st[2] += 1;
+    }
+#endif
+    return s;
+}
+// M rows of a lane's two references in pass A (ranks 0..63) / pass B (ranks 64..127); 64 = the dump row
+__device__ __forceinline__ int sc2_row_a(int rx) { return rx < 64 ? rx : 64; }
+__device__ __forceinline__ int sc2_row_b(int rx) {
+    const unsigned d = (unsigned)(rx - 64);
+    return (int)(d < 64u ? d : 64u);
+}
+
+// operands of the combine GEMM G[64 rows x 32 ch] = M[64 x 32 samples] Q[32 x 32]: A from the rows of M, B from Qs
+struct ScA16 {
+    h8_t ah[2][2], al[2][2];  // [row tile][k-step]: 8 samples 16 ks + 8 hi .. + 7 of row 32 m + i
+};
+struct ScB16 {
+    float bs[2][8];  // raw (dead after sc2_split_b)
+    h8_t bh[2], bl[2];
+    float bun;
+};
+struct ScA32 {
+    f32x4 a4[2][4];
+};
+struct ScB32 {
+    float bq[16];
+};
+// (n: rows in use, wave-uniform -- the second row tile is read / multiplied only when n > 32)
+__device__ __forceinline__ void sc2_load_a(const float* M, int i, int hi, int n, ScA16& A) {
+    const half_t* Mh = reinterpret_cast<const half_t*>(M);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (m == 1 && n <= 32) break;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const half_t* a = Mh + (32 * m + i) * M16_RS + 16 * ks + 8 * hi;
+            A.ah[m][ks] = *reinterpret_cast<const h8_t*>(a);
+            A.al[m][ks] = *reinterpret_cast<const h8_t*>(a + M16_PLANE);
+        }
+    }
+}
+__device__ __forceinline__ void sc2_load_a(const float* M, int i, int hi, int n, ScA32& A) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (m == 1 && n <= 32) break;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+            A.a4[m][t4] = *reinterpret_cast<const f32x4*>(M + (32 * m + i) * MS + 16 * hi + 4 * t4);
+    }
+}
+__device__ __forceinline__ void sc2_load_b(const float* Qs, int i, int hi, ScB16& B) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) B.bs[ks][j] = Qs[(16 * ks + 8 * hi + j) * 33 + i];
+}
+__device__ __forceinline__ void sc2_load_b(const float* Qs, int i, int hi, ScB32& B) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) B.bq[t] = Qs[(t + 16 * hi) * 33 + i];
+}
+__device__ __forceinline__ void sc2_split_b(ScB32&) {}
+// per-channel normalisation of the B operand to the top of the fp16 range (column = this lane and lane ^ 32) + split
+__device__ __forceinline__ void sc2_split_b(ScB16& B) {
+    const float (&bs)[2][8] = B.bs;
+    float mx = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, __builtin_fabsf(bs[ks][j]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    int E = (int)(__builtin_bit_cast(unsigned, mx) >> 23);
+    E = E < 16 ? 16 : (E > 240 ? 240 : E);
+    const float bsc = __builtin_bit_cast(float, (unsigned)(268 - E) << 23);
+    B.bun = __builtin_bit_cast(float, (unsigned)(E - 14) << 23);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = bs[ks][2 * j] * bsc, x1 = bs[ks][2 * j + 1] * bsc;
+            h2_t ph, pq;
+            split_pair(x0, x1, ph, pq);
+            B.bh[ks][2 * j] = ph.x;
+            B.bh[ks][2 * j + 1] = ph.y;
+            B.bl[ks][2 * j] = pq.x;
+            B.bl[ks][2 * j + 1] = pq.y;
+        }
+}
+__device__ __forceinline__ void sc2_gemm(const ScA16& A, const ScB16& B, int n, f32x16& acc0, f32x16& acc1) {
+    acc0 = f32x16 ZERO16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.ah[0][ks], B.bh[ks], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.ah[0][ks], B.bl[ks], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.al[0][ks], B.bh[ks], acc0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] *= B.bun;
+    if (n > 32) {
+        acc1 = f32x16 ZERO16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.ah[1][ks], B.bh[ks], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.ah[1][ks], B.bl[ks], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.al[1][ks], B.bh[ks], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] *= B.bun;
+    }
+}
+__device__ __forceinline__ void sc2_gemm(const ScA32& A, const ScB32& B, int n, f32x16& acc0, f32x16& acc1) {
+    acc0 = f32x16 ZERO16;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.a4[0][t >> 2][t & 3], B.bq[t], acc0, 0, 0, 0);
+    if (n > 32) {
+        acc1 = f32x16 ZERO16;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.a4[1][t >> 2][t & 3], B.bq[t], acc1, 0, 0, 0);
+    }
+}
+// flush rows 0 .. n-1 (rounded up to a group of 8): one 128-byte atomic per row pair, straight from the accumulators
+// (row of register 4 g + e = LIDX: e + 8 g + 4 hi); ct: the compacted tags of these rows
+__device__ __forceinline__ void sc2_flush(const f32x16& acc0, const f32x16& acc1, const int* ct, int n,
+                                          __amdgpu_buffer_rsrc_t grsrc, unsigned lane_b, int hi) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (TT_SC2_FLUSH_ALL || n > 8 * g) {
+            const i32x4 k0 = *reinterpret_cast<const i32x4*>(ct + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2)
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc0[4 * g + e2], grsrc,
+                                                                (int)(((unsigned)k0[e2] << 7) | lane_b), 0, 0);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (TT_SC2_FLUSH_ALL || n > 32 + 8 * g) {
+            const i32x4 k1 = *reinterpret_cast<const i32x4*>(ct + 32 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2)
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc1[4 * g + e2], grsrc,
+                                                                (int)(((unsigned)k1[e2] << 7) | lane_b), 0, 0);
+        }
+    }
+}
+
+// prep(pl, refs): corner set-up of plane pl for this lane's sample AND the staging of its row of Q, scaled by refs.qs,
+// into Qs[j*33 + ch] (the previous plane's B operand is in registers by then).  M: all-zero on entry and on exit.
+// tags: the 32 dummy words (scatter_init_tags).  Ls: 256 floats of lost-reference lists, followed by SC2_INTS ints.
+// Pipeline per plane p:  operands A(p) -> registers, M rows back to zero, [n > 64: rows of pass B -> M]; prep(p+1);
+//   GEMM A(p); [pass B: flush A(p), operands B(p) -> registers, M back to zero]; claims + ranks(p+1), lost references of
+//   p+1 (under the MFMAs); [pass B: GEMM B(p), flush B(p) | else: flush A(p)]; rows of pass A(p+1) -> M.
+template <bool EXACT, class Prep>
+__device__ __forceinline__ void scatter_planes(float* __restrict__ grad, unsigned grad_bytes, const float* Qs, float* M,
+                                               int* tags, float* Ls, int i, int hi, Prep&& prep,
+                                               unsigned long long* st = nullptr) {
+    // BUFFER atomics with a 32-bit BYTE offset (texel << 7 | channel * 4) from the gradient copy: a tag of -1 gives the
+    // offset 0xFFFFFF80 + 4 ch, beyond num_records (the host refuses gradient buffers of 4 GB - 256 B and more), and the
+    // hardware range check drops the atomic -- no compare, no exec-mask branch per row.
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(grad, 0, (int)grad_bytes, 0x00020000);
+    const unsigned lane_b = 4u * (unsigned)i;
+    const int lane = i + 32 * hi;
+    int* const dummy = tags + i;
+    int* const htab = reinterpret_cast<int*>(Ls + 256);
+    int* const ctag = htab + SC2_HT;
+    int* const cdump = ctag + 2 * SC2_CT;
+    typedef typename std::conditional<EXACT, ScA32, ScA16>::type AOp;
+    typedef typename std::conditional<EXACT, ScB32, ScB16>::type BOp;
+#ifdef TT_TUNING  // sub-phase cycles of the epilogue (st[3..5] = operands+prep / GEMM+claim / flush+reset+lost)
+    unsigned long long sp_t = __builtin_amdgcn_s_memtime();
+#define TT_SUBPHASE(k)                                                    \
+    do {                                                                  \
+        if (st) {                                                         \
+            __builtin_amdgcn_sched_barrier(0);                            \
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+            st[k] += t_now - sp_t;                                        \
+            sp_t = t_now;                                                 \
+            __builtin_amdgcn_sched_barrier(0);                            \
+        }                                                                 \
+    } while (0)
+#elif defined(TT_SC2_FENCE)
+#define TT_SUBPHASE(k) __builtin_amdgcn_sched_barrier(0)
+#else
+#define TT_SUBPHASE(k) \
+    do {               \
+    } while (0)
+#endif
+    {  // the table starts empty (its LDS is shared with the other phases of the tile step)
+        const i32x4 e4 = {-1, -1, -1, -1};
+        *reinterpret_cast<i32x4*>(htab + 4 * lane) = e4;
+    }
+    PlaneRefs rc, rn;
+    Sc2State sc, sn;
+    prep(0, rc);
+    sc = sc2_claim_rank(rc, htab, ctag, cdump, dummy, lane, st);
+    scatter_lost(rc, sc.l0, sc.l1, Qs, Ls, grsrc, i, hi);
+    m_store<EXACT>(M, sc2_row_a(sc.rx0), i, rc.c0);
+    m_store<EXACT>(M, sc2_row_a(sc.rx1), i, rc.c1);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const int* const ct = ctag + SC2_CT * (pl & 1);
+        int* const ct_next = ctag + SC2_CT * ((pl + 1) & 1);
+        const bool pass_b = TT_SC2_NO_PASSB ? false : sc.n > 64;  // wave-uniform
+        f32x16 acc0, acc1;
+        AOp A;
+        BOp B;
+        sc2_load_a(M, i, hi, sc.n, A);
+        m_zero<EXACT>(M, sc2_row_a(sc.rx0), i);
+        m_zero<EXACT>(M, sc2_row_a(sc.rx1), i);
+        if (pass_b) {
+            m_store<EXACT>(M, sc2_row_b(sc.rx0), i, rc.c0);
+            m_store<EXACT>(M, sc2_row_b(sc.rx1), i, rc.c1);
+        }
+        sc2_load_b(Qs, i, hi, B);
+        if (pl < 2) prep(pl + 1, rn);
+        sc2_split_b(B);
+        sc2_gemm(A, B, sc.n, acc0, acc1);
+        TT_SUBPHASE(3);
+        if (pass_b) {  // (rare on dense rays: the first pass is flushed before the next plane's claims)
+            sc2_flush(acc0, acc1, ct, 64, grsrc, lane_b, hi);
+            sc2_load_a(M, i, hi, sc.n - 64, A);
+            m_zero<EXACT>(M, sc2_row_b(sc.rx0), i);
+            m_zero<EXACT>(M, sc2_row_b(sc.rx1), i);
+        }
+        if (pl < 2) sn = sc2_claim_rank(rn, htab, ct_next, cdump, dummy, lane, st);
+        TT_SUBPHASE(4);
+        if (pass_b) {
+            sc2_gemm(A, B, sc.n - 64, acc0, acc1);
+            sc2_flush(acc0, acc1, ct + 64, sc.n - 64, grsrc, lane_b, hi);
+        } else {
+            sc2_flush(acc0, acc1, ct, sc.n, grsrc, lane_b, hi);
+        }
+        if (pl < 2) {
+            scatter_lost(rn, sn.l0, sn.l1, Qs, Ls, grsrc, i, hi);
+            m_store<EXACT>(M, sc2_row_a(sn.rx0), i, rn.c0);
+            m_store<EXACT>(M, sc2_row_a(sn.rx1), i, rn.c1);
+            rc = rn;
+            sc = sn;
+        }
+        TT_SUBPHASE(5);
+    }
+}
+#endif  // TT_SCATTER_V1
 
 struct MlpGradPtrs {
     float* w1;
@@ -716,7 +952,7 @@ struct MlpGradPtrs {
     float* v3;
 };
 
-// ---- texture half: parameters and weight-image map shared by tt_backward_tex.hip and tt_backward_tex2.hip ----
+// ---- texture half: parameters and weight-image map of tt_backward_tex.hip ----
 struct BwdTexParams {
     const float* packed;
     MlpPtrs w;
@@ -764,9 +1000,6 @@ template <int PREC>
 struct TexWFloats {
     static constexpr int value = PREC == PREC_S3 ? TEX_W3P_FLOATS : TEX_W16_FLOATS;
 };
-#ifdef TT_TUNING
-void tt_launch_bwd_tex2(const BwdTexParams& p, int cus, hipStream_t s);  // tt_backward_tex2.hip (tuning build only)
-#endif
 
 // =====================================================================================================
 // host side

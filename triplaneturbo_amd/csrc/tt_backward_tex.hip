@@ -383,14 +383,6 @@ static void launch_bwd_tex(const BwdTexParams& p0, long long blocks, hipStream_t
             const long long n = p.cfg.n_rays * p.cfg.n_samples * 3;
             hipLaunchKernelGGL(k_absmax1, dim3(absmax_blocks(n)), dim3(256), 0, s, p.g_features, n, bnd + TT_BOUND_UP1);
         }
-#ifdef TT_TUNING
-        // tuning build only: the experimental wave-pair kernel of round 4 (tt_backward_tex2.hip: two waves per SIMD; correct,
-        // 1.4x slower than the one-wave-per-tile kernel), two-piece mode, render path
-        if (p.weights && prec == PREC_S2 && (p.cfg.flags & TT_R_BWD_PAIR) && !(p.cfg.flags & TT_R_BWD_SOLO)) {
-            tt_launch_bwd_tex2(p, tt_num_cus(), s);
-            return;
-        }
-#endif
         if (prec == PREC_S3)
             LAUNCH_TEX(PREC_S3, true);
         else

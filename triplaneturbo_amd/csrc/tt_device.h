@@ -189,7 +189,7 @@ struct Corners {
     float w[4];   // bilinear weights nw, ne, sw, se (0 when out of bounds)
     float du[4];  // d w / d ix   (0 when out of bounds)
     float dv[4];  // d w / d iy
-    int hs[4];    // 8x8 torus hash of the texel (y&7)*8 + (x&7): slot in the write-combining window
+    int hs[4];    // 16x16 torus hash of the texel (y&15)*16 + (x&15): entry of the scatter's texel table
     bool any;     // any corner in bounds
     int inmask;   // bit k: corner k in bounds (d2 w_k / d ix d iy = +1, -1, -1, +1 there, 0 elsewhere)
 };
@@ -242,10 +242,10 @@ __device__ __forceinline__ void corners_setup(float gx, float gy, int H, int W, 
     c.off[2] = yc1 + xc0;
     c.off[3] = yc1 + xc1;
     const float i0 = bx0 * by0, i1 = bx1 * by0, i2 = bx0 * by1, i3 = bx1 * by1;  // (only the points-gradient kernel)
-    c.hs[0] = ((y0 & 7) << 3) | (x0 & 7);
-    c.hs[1] = ((y0 & 7) << 3) | ((x0 + 1) & 7);
-    c.hs[2] = (((y0 + 1) & 7) << 3) | (x0 & 7);
-    c.hs[3] = (((y0 + 1) & 7) << 3) | ((x0 + 1) & 7);
+    c.hs[0] = ((y0 & 15) << 4) | (x0 & 15);
+    c.hs[1] = ((y0 & 15) << 4) | ((x0 + 1) & 15);
+    c.hs[2] = (((y0 + 1) & 15) << 4) | (x0 & 15);
+    c.hs[3] = (((y0 + 1) & 15) << 4) | ((x0 + 1) & 15);
     c.any = (bx0 + bx1) * (by0 + by1) != 0.f;
     c.inmask = (int)i0 | ((int)i1 << 1) | ((int)i2 << 2) | ((int)i3 << 3);
 }

@@ -800,8 +800,9 @@ int tt_validate_cfg(const tt_render_cfg* cfg) {
         const int pbits = cfg->flags & (TT_R_EXACT_F32 | TT_R_SPLIT2 | TT_R_SPLIT3);
         if (pbits & (pbits - 1)) return TT_ERR_BAD_ARG;
     }
+    if (cfg->flags & TT_R_BWD_PAIR) return TT_ERR_UNSUPPORTED;  // reserved (the wave-pair kernel left the tree in round 6)
 #ifndef TT_TUNING
-    if (cfg->flags & (TT_R_WGRAD_F32 | TT_R_BWD_PAIR)) return TT_ERR_UNSUPPORTED;  // dev A/B kernels: tuning build only
+    if (cfg->flags & TT_R_WGRAD_F32) return TT_ERR_UNSUPPORTED;  // dev A/B kernel: tuning build only
 #endif
     if (!(cfg->skip_eps_tex >= 0.f) || !(cfg->skip_eps_geo >= 0.f)) return TT_ERR_BAD_ARG;
     return TT_OK;

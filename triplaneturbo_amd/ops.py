@@ -114,7 +114,6 @@ class RenderConfig:
     precision: Optional[str] = None
     exact_f32: bool = False
     wgrad_f32: bool = False  # TT_R_WGRAD_F32: tuning build only (the product library rejects it)
-    bwd_pair: bool = False  # TT_R_BWD_PAIR: tuning build only (the product library rejects it)
     # TT_R_VOLSDF: alpha = |dists| x VolSDF density instead of the NeuS alpha (neus_volume_renderer.py:19-23,:95-96)
     use_volsdf: bool = False
 
@@ -381,7 +380,7 @@ def _make_cfg(packed: Tensor, n_rays: int, rays_per_view: int, n_samples: int, r
     return _lib.RenderCfg(P, n_views // P, H, W, rays_per_view, n_samples, n_rays, rc.radius, rc.sdf_bias_radius,
                           inv_std, rc.cos_anneal_ratio, rc.rgb_grad_shrink,
                           (_lib.TT_R_PER_SAMPLE if per_sample else 0) | _lib.r_flag(rc.prec) |
-                          (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0) | (_lib.TT_R_BWD_PAIR if rc.bwd_pair else 0) |
+                          (_lib.TT_R_WGRAD_F32 if rc.wgrad_f32 else 0) |
                           (_lib.TT_R_VOLSDF if rc.use_volsdf else 0),
                           image_w if (image_w > 0 and rays_per_view % image_w == 0) else 0, int(rc.tile_sb),
                           max(1, int(rc.grad_copies)), max(0, int(rc.tile_chunk)), max(0.0, float(rc.skip_eps_tex)),
