@@ -152,7 +152,13 @@ typedef struct {
  *   TT_R_SPLIT3     fp32-GRADE products on the fp16 matrix pipe: every operand is split EXACTLY in three fp16 pieces
  *                   (hi + mid + lo = v), the six product terms above 2^-33 are accumulated in fp32 (6 x
  *                   v_mfma_f32_32x32x16_f16 per k-step).  Product error <= 2^-24 of sum |a b| (tools/mfma16_probe.hip):
- *                   the reference's precision at ~1/3 of the fp32 MFMA's matrix-pipe time.
+ *                   the reference's precision at ~1/3 of the fp32 MFMA's matrix-pipe time.  SCOPE: the mat-vec chains of
+ *                   every kernel (forward, recompute, both gradient chains, per-point queries, eval, d/d points) are
+ *                   three-piece; the REDUCTIONS OVER SAMPLES of the backward -- the weight-gradient outer products and
+ *                   the scatter's combine GEMM -- use TWO-piece operands (hi + lo, all four cross terms, per-launch /
+ *                   per-sample power-of-two scales): each operand is represented to 2^-23 and the round-to-nearest
+ *                   errors average over the thousands to millions of samples such a sum runs over (measured: weight
+ *                   and plane gradients 4e-7 ... 1e-6 from the fp32 oracle in all three modes).
  *   TT_R_EXACT_F32  every product on the fp32-input MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain).  The A/B
  *                   reference of the split modes.
  *   TT_R_SPLIT2     the FAST mode (the default of rounds 2-4): two fp16 pieces per operand, three product terms, ~2^-21.5

@@ -769,12 +769,16 @@ def init_mlp_weights(dims: Sequence[int], gen: torch.Generator, dtype=torch.floa
 
 
 def synthetic_loss(out: Dict[str, Tensor], proj: Dict[str, Tensor], lambda_sparsity: float = 1.0,
-                   lambda_eikonal: float = 1.0) -> Tensor:
+                   lambda_eikonal: float = 1.0, sample_mask: Optional[Tensor] = None) -> Tensor:
     """Fixed scalar loss of SURVEY.md G6: seeded random projections of the image-space outputs
-    + sparsity (multiprompt_dual_renderer_multistep_generator.py:635) + eikonal (:696-699)."""
+    + sparsity (multiprompt_dual_renderer_multistep_generator.py:635) + eikonal (:696-699).
+    sample_mask (N,) of 0/1 (the fuzz only): samples that leave the eikonal mean (their term counts as 0)."""
     loss = 0.0
     for k, p in proj.items():
         loss = loss + (out[k] * p).sum()
     loss = loss + lambda_sparsity * (out["opacity"] ** 2 + 0.01).sqrt().mean()
-    loss = loss + lambda_eikonal * ((torch.linalg.norm(out["sdf_grad"], ord=2, dim=-1) - 1.0) ** 2).mean()
+    eik = (torch.linalg.norm(out["sdf_grad"], ord=2, dim=-1) - 1.0) ** 2
+    if sample_mask is not None:
+        eik = eik * sample_mask.to(eik.dtype).to(eik.device).reshape(eik.shape)
+    loss = loss + lambda_eikonal * eik.mean()
     return loss

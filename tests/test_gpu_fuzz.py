@@ -36,8 +36,9 @@ def _case(seed):
     return P, n_view, R, Hh, Ww, S, rc, knobs, near, far, jittered
 
 
-# 400 seeds in the suite since round 5 (round 4 ran them once, outside the suite); TT_FUZZ_SEEDS=N overrides
-N_SEEDS = int(os.environ.get("TT_FUZZ_SEEDS", "400"))
+# 1 400 seeds in the suite since round 6 (round 5: 400; ~200 s on one MI355X); TT_FUZZ_SEEDS=N overrides
+N_SEEDS = int(os.environ.get("TT_FUZZ_SEEDS", "1400"))
+_SUITE = {}  # seed -> summary of parity.check_grads (suite gates: test_fuzz_suite_statistics below)
 N_SEEDS_AUX = min(N_SEEDS, 48) // 2  # the point-query and eval fuzzes
 
 
@@ -61,12 +62,17 @@ def test_random_configuration_matches_oracle(mods, seed):
     # rays with a sample on a ReLU kink of the sdf net leave the loss (parity.kink_free_rays: the normal is not defined to
     # fp32 accuracy there, one such sample moves the gradients of a 20-ray scene by 1e-3); typically 0 ... 3 % of the rays
     keep = kink_free_rays(cache, sw, fw, ro, rd, ts, te, n_view)
+    # round 6: ... nor on a kink of the FEATURE network (same criterion on the texture encoding: d relu is a step, one such
+    # sample moves d loss / d V1, V2 of a 200-sample scene by 1e-3 whichever side an evaluation lands on -- seed 1394 of round
+    # 5's 1 400-seed run), and a masked ray leaves the EIKONAL term too (it runs over every sample's sdf_grad: seed 491)
+    keep &= kink_free_rays(cache, sw, fw, ro, rd, ts, te, n_view, net="feature")
     proj = {n: v * keep.view(P * n_view, Hh, Ww, 1).to(v.dtype) for n, v in proj.items()}
-    out, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, dict(rck, **knobs))
-    o32, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
-    o64, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
-    # the fp32 oracle once more in its second operation order: |g32 - g32a| = the order sensitivity of fp32 on this scene
-    g32a = [_oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck, alt_order=lv)[2] for lv in (1, 2, 3)]
+    smask = keep.view(-1, 1).expand(-1, S).reshape(-1).float()
+    out, l_hip, g_hip = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, dict(rck, **knobs), sample_mask=smask)
+    o32, l32, g32 = _oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck, sample_mask=smask)
+    o64, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck, sample_mask=smask)
+    # the fp32 oracle three more times in other operation orders: their mutual distances = the order sensitivity of fp32 here
+    g32a = [_oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck, alt_order=lv, sample_mask=smask)[2] for lv in (1, 2, 3)]
     case = f"test_gpu_fuzz[{seed}] P{P} v{n_view} R{R} {Hh}x{Ww} S{S} {rck} {knobs}"
     km = keep.view(P * n_view, Hh, Ww, 1)
     masked = lambda o: {k: o[k].detach().cpu().reshape(P * n_view, Hh, Ww, -1) * km.to(o[k].dtype) for k, _ in KEYS}  # noqa: E731
@@ -86,15 +92,69 @@ def test_random_configuration_matches_oracle(mods, seed):
         for other in ("split3", "f32", "split2"):
             if other != knobs["precision"]:
                 _, _, g_x = _hip_grads(mods, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj,
-                                       dict(rck, **dict(knobs, precision=other)))
+                                       dict(rck, **dict(knobs, precision=other)), sample_mask=smask)
                 for i in far:
                     twin[names[i]][other + "_vs_fp32"] = rel(g_x[i], g32[i])
         report(case + " [same inputs, other precision modes]", twin)
-    check_grads(case + f" kink-free rays {int(keep.sum())}/{keep.numel()}", [g_hip[i] for i in nz], [g32[i] for i in nz],
-                [g64[i] for i in nz], names=[names[i] for i in nz], elem=False,
-                g32_alt=[[ga[i] for i in nz] for ga in g32a], fast=knobs["precision"] == "split2")
+    summ = {"mode": knobs["precision"]}
+    _SUITE[seed] = summ
+    try:
+        check_grads(case + f" kink-free rays {int(keep.sum())}/{keep.numel()}", [g_hip[i] for i in nz], [g32[i] for i in nz],
+                    [g64[i] for i in nz], names=[names[i] for i in nz], elem=False,
+                    g32_alt=[[ga[i] for i in nz] for ga in g32a], fast=knobs["precision"] == "split2", summary=summ)
+    except AssertionError:
+        summ["failed"] = True
+        raise
     for i in set(range(7)) - set(nz):
         assert float(g_hip[i].abs().max()) == 0.0, (case, names[i])
+
+
+def test_fuzz_suite_statistics():
+    """Suite gates of tests/parity.py (rule 3), over the seeds that ran in this process: the exception path must stay an
+    exception.  (a) a seed may miss the PLAIN 1e-4 against the primary fp32 oracle only where the fp32 evaluations disagree
+    among themselves (or on a kink, within 1e-4 of fp64); (b) >= SUITE_PLAIN_FRAC of all seeds meet it, p90 / p99 of the
+    per-seed worst |hip - fp32| / |fp32| <= SUITE_P90 / SUITE_P99.  Written to the parity report and to
+    gpurun_out/parity_summary.json (copied to profiles/ per round)."""
+    import json
+
+    import numpy as np
+    from parity import ORDER_K, ROOT, SUITE_P90, SUITE_P99, SUITE_PLAIN_FRAC
+    done = {s: v for s, v in _SUITE.items() if "worst_hip_vs_fp32" in v}
+    if len(done) < 200:
+        pytest.skip(f"suite statistics need >= 200 fuzz seeds in one process ({len(done)} ran)")
+    worst = np.array([v["worst_hip_vs_fp32"] for v in done.values()])
+    plain = np.array([bool(v["plain"]) for v in done.values()])
+    exc = {s: v for s, v in done.items() if not v["plain"]}
+    # gate (a): a seed may miss the plain bar only where the fp32 evaluations disagree among themselves (or on a kink: within
+    # 1e-4 of the exact math)
+    agree = {s: v for s, v in done.items() if v["max_sens"] <= TOL_VS_FP32 / ORDER_K}
+    unexplained = sorted(s for s, v in agree.items() if not v["plain"] and v["worst_hip_vs_fp64"] > TOL_VS_FP32)
+    by_mode = {}
+    for m in ("split3", "f32", "split2"):
+        w = np.array([v["worst_hip_vs_fp32"] for v in done.values() if v["mode"] == m])
+        if len(w):
+            by_mode[m] = {"seeds": int(len(w)), "plain_frac": float((w <= TOL_VS_FP32).mean()),
+                          "p50": float(np.percentile(w, 50)), "p90": float(np.percentile(w, 90)),
+                          "p99": float(np.percentile(w, 99)), "max": float(w.max())}
+    summary = {"seeds": int(len(done)), "failed": sorted(s for s, v in _SUITE.items() if v.get("failed")),
+               "plain_frac": float(plain.mean()), "p50": float(np.percentile(worst, 50)),
+               "p90": float(np.percentile(worst, 90)), "p99": float(np.percentile(worst, 99)), "max": float(worst.max()),
+               "gates": {"plain_frac_min": SUITE_PLAIN_FRAC, "p90_max": SUITE_P90, "p99_max": SUITE_P99},
+               "fp32_evaluations_agree": {"seeds": int(len(agree)), "plain": int(sum(bool(v["plain"]) for v in agree.values())),
+                                          "unexplained": unexplained},
+               "by_mode": by_mode,
+               "exceptions": {str(s): {"mode": v["mode"], "worst_hip_vs_fp32": v["worst_hip_vs_fp32"],
+                                       "worst_hip_vs_fp64": v["worst_hip_vs_fp64"], "fp32_order_sensitivity": v["max_sens"],
+                                       "passed_by": v["passed_by"]} for s, v in sorted(exc.items())}}
+    report("test_gpu_fuzz suite statistics", summary)
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "parity_summary.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+    except OSError:
+        pass
+    assert not unexplained, summary
+    assert summary["plain_frac"] >= SUITE_PLAIN_FRAC, summary
+    assert summary["p90"] <= SUITE_P90 and summary["p99"] <= SUITE_P99, summary
 
 
 @pytest.mark.parametrize("seed", range(N_SEEDS_AUX))

@@ -335,3 +335,49 @@ def test_load_never_binds_a_stale_library_silently(monkeypatch):
     monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
     with pytest.raises(RuntimeError, match="different sources"):
         _lib.load()
+
+
+def test_concurrent_builds_are_serialised(tmp_path):
+    """load() rebuilds a stale library, so a multi-rank launch on an edited checkout sends every rank into
+    build() at once.  They must serialise on the lock file and only ONE of them may compile: the second finds the library
+    up to date.  (A stand-in for hipcc that logs its invocations and copies the hash marker; no GPU, no real compile.)"""
+    import subprocess
+    import sys
+    import textwrap
+    from triplaneturbo_amd import _lib
+    fake = tmp_path / "fake_hipcc"
+    log = tmp_path / "calls.log"
+    fake.write_text(textwrap.dedent(f"""\
+        #!{sys.executable}
+        import sys, time, re
+        a = sys.argv[1:]
+        open({str(log)!r}, "a").write("call\\n")
+        time.sleep(0.3)
+        out = a[a.index("-o") + 1]
+        if "-c" in a:
+            h = [x for x in a if x.startswith("-DTT_SOURCE_HASH_STR=")][0].split("=", 1)[1].strip('"')
+            open(out, "w").write("TT_SOURCE_HASH=" + h)
+        else:
+            objs = [x for x in a if x.endswith(".o")]
+            open(out, "w").write(open(objs[0]).read())
+        """))
+    fake.chmod(0o755)
+    variant = f"locktest{os.getpid()}"
+    code = (f"from triplaneturbo_amd import _lib; print(_lib.build(variant={variant!r}, defines=['-DLOCKTEST'], "
+            f"source_flags={{}}))")
+    env = dict(os.environ, HIPCC=str(fake), PYTHONPATH=ROOT)
+    out_path = os.path.join(os.path.dirname(_lib.LIB_PATH), f"libtt_hip_{variant}.so")
+    try:
+        procs = [subprocess.Popen([sys.executable, "-c", code], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True) for _ in range(3)]
+        res = [p.communicate(timeout=120) for p in procs]
+        assert all(p.returncode == 0 for p in procs), res
+        n_calls = len(open(log).read().split())
+        assert n_calls == len(_lib._sources()) + 1, (n_calls, res)  # one compile per unit + one link, ONCE
+        assert _lib.embedded_hash(out_path) == _lib.source_hash(False, ["-DLOCKTEST"], {})
+        leftovers = [f for f in os.listdir(os.path.dirname(out_path)) if f.endswith(".tmp")]
+        assert not leftovers, leftovers
+    finally:
+        for f in (out_path, os.path.join(os.path.dirname(out_path), "build", os.path.basename(out_path) + ".lock")):
+            if os.path.exists(f):
+                os.unlink(f)

@@ -314,12 +314,10 @@ def test_volsdf_random_configuration_matches_oracle(seed):
     o64, l64, g64 = _oracle_grads(torch.float64, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck)
     g32a = [_oracle_grads(torch.float32, cache, sw, fw, ro, rd, ts, te, bg, cd, c2w, proj, rck, alt_order=lv)[2]
             for lv in (1, 2, 3)]
-    # Here the EXACT evaluation joins the set of reference evaluations of parity.check_grads (nearest-evaluation rule, measured
-    # sensitivity = largest pairwise distance).  Without a surface clip the normals accumulated inside the volume nearly cancel
-    # on some rays, comp_normal's normalisation amplifies the rounding of the per-sample weights, and all four fp32 evaluations
-    # -- they share those roundings -- sit together 5e-4 from the exact gradients while differing by 1e-5 among themselves
-    # (seed 28; the HIP gradients are 1.2e-5 from fp64 there).  Being within the bar of the exact math is not a miss.
-    g32a.append([t.float() for t in g64])
+    # (The EXACT evaluation is a member of the reference set of parity.check_grads' exception rule since round 6.  Without a
+    # surface clip the normals accumulated inside the volume nearly cancel on some rays, comp_normal's normalisation amplifies
+    # the rounding of the per-sample weights, and all four fp32 evaluations -- they share those roundings -- sit together 5e-4
+    # from the exact gradients while differing by 1e-5 among themselves (seed 28; the HIP gradients are 1.2e-5 from fp64 there).)
     case = f"test_volsdf_fuzz[{seed}] P{P} v{n_view} R{R} {Hh}x{Ww} S{S} {rck} {knobs}"
     km = keep.view(P * n_view, Hh, Ww, 1)
     masked = lambda o: {k: o[k].detach().cpu().reshape(P * n_view, Hh, Ww, -1) * km.to(o[k].dtype) for k, _ in GK}  # noqa: E731

@@ -140,8 +140,30 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, vari
         out = os.path.join(_HERE, f"libtt_hip_{variant}.so")
     if not force and not needs_build(out, tuning, defines, source_flags):
         return out
+    # One builder at a time per output file: a multi-rank launch on a stale checkout (every rank's load() lands here) must not
+    # compile and link concurrently into the same paths.  The ranks serialise on an fcntl lock next to the library; whoever
+    # gets it SECOND finds the library up to date and returns.  Objects go to a per-process directory, the link to a
+    # per-process temporary that os.replace() moves into place atomically.
+    import fcntl
+    import shutil
+    os.makedirs(os.path.join(_HERE, "build"), exist_ok=True)
+    with open(os.path.join(_HERE, "build", os.path.basename(out) + ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build(out, tuning, defines, source_flags):
+                return out
+            objdir = os.path.join(_HERE, "build", (variant or ("tuning" if tuning else "release")) + f".{os.getpid()}")
+            try:
+                return _build_locked(out, objdir, verbose, tuning, defines, source_flags)
+            finally:
+                shutil.rmtree(objdir, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(out: str, objdir: str, verbose: bool, tuning: bool, defines: Optional[List[str]],
+                  source_flags: Optional[dict]) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(_HERE, "build", variant or ("tuning" if tuning else "release"))
     os.makedirs(objdir, exist_ok=True)
     digest = source_hash(tuning, defines, source_flags)
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DTT_TUNING"] if tuning else []) + list(defines or [])
@@ -160,13 +182,15 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, vari
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed ({pr.returncode}):\n{so}\n{se}")
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", out + ".tmp"]
+    tmp = f"{out}.{os.getpid()}.tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc link failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
-    os.replace(out + ".tmp", out)
-    if embedded_hash(out) != digest:
+    if embedded_hash(tmp) != digest:
+        os.unlink(tmp)
         raise RuntimeError(f"{out} does not carry the source hash it was built with")
+    os.replace(tmp, out)
     return out
 
 

@@ -20,7 +20,10 @@ __device__ __forceinline__ float rcp_(float x) {
 #ifdef TT_FAST_RCP  // (dev A/B: rounds 1-4)
     return r;
 #else
-    return fmaf(fmaf(-x, r, 1.f), r, r);
+    // (x = 0, +-inf or a denormal: r is inf / 0 and the refinement would be inf * 0 = NaN -- keep the hardware's r, as the
+    // reference's IEEE quotient gives inf / 0 there; one NaN test, no lane-mask combination)
+    const float nr = fmaf(fmaf(-x, r, 1.f), r, r);
+    return nr == nr ? nr : r;
 #endif
 }
 // logistic function 1 / (1 + exp(-x)) on the hardware exp2 + reciprocal, to ~2 ulp: the argument t = -x log2(e) is carried
@@ -31,6 +34,9 @@ __device__ __forceinline__ float sigmoid_(float x) {
 #ifdef TT_FAST_LOGISTIC  // (dev A/B: rounds 1-4)
     return rcp_(1.f + __builtin_amdgcn_exp2f(x * -1.44269504f));
 #endif
+    // |x| > 128 saturates like torch.sigmoid (an overflowing sdf * inv_std, +-inf: t_lo would be inf - inf); a NaN stays a NaN
+    x = x < -128.f ? -128.f : x;
+    x = x > 128.f ? 128.f : x;
     const float c_hi = -1.44269504f, c_lo = -1.92596303e-8f;  // -log2(e) = c_hi + c_lo
     const float t_hi = fminf(x * c_hi, 126.f);
     const float t_lo = fmaf(x, c_hi, -(x * c_hi)) + x * c_lo;

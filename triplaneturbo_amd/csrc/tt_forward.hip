@@ -620,7 +620,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
             sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
             const float X = scale_coord(px, dc.radius), Y = scale_coord(py, dc.radius), Z = scale_coord(pz, dc.radius);
             // live = ray_ok && !(T < eps_T) as a product of 0/1 factors, then ONE compare (eps_T = 0: always live)
-            const float livef = ray_okf * (T < p.eps_T ? 0.f : 1.f);
+            const float livef = ray_okf * (__builtin_fabsf(T) < p.eps_T ? 0.f : 1.f);
             const bool live = livef != 0.f;
             float s0, gq[3];
             decode_geo_fwd<true, PREC>(L, dc, X, Y, Z, live, i, hi, s0, gq);
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
             nz = fmaf(wgt, uz, nz);
             // want_tex = live && wgt > eps_w: wgt = alpha T is exactly 0 on a dead lane (alpha = 0 above) and eps_w >= 0,
             // so the weight test alone decides (eps_w = 0: every sample with a non-zero weight)
-            const bool want_tex = wgt > p.eps_w;
+            const bool want_tex = __builtin_fabsf(wgt) > p.eps_w;  // (|.|: VolSDF alphas are not clipped, T and the weights can change sign)
             if (__any(want_tex)) {
                 float c[3];
                 decode_tex_fwd<PREC>(L, dc, X, Y, Z, want_tex, i, hi, c);
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
                     cb = fmaf(wgt, sigmoid_(c[2]) * 1.002f - 0.001f, cb);
                 }
             }
-            if (p.eps_T > 0.f && !__any(ray_okf * (T < p.eps_T ? 0.f : 1.f) != 0.f)) break;  // every ray is opaque
+            if (p.eps_T > 0.f && !__any(ray_okf * (__builtin_fabsf(T) < p.eps_T ? 0.f : 1.f) != 0.f)) break;  // every ray is opaque
         }
         if (ray_ok && hi == 0) {
             p.opacity[ray] = op;

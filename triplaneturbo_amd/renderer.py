@@ -221,6 +221,7 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         grad_on = torch.is_grad_enabled()  # the reference stays differentiable in eval mode too
         packed = kwargs.pop("packed", None)  # PatchRenderer packs once for its two renders
         tile_sb = kwargs.pop("tile_sb", None)  # PatchRenderer: its sparse global render and its dense patch differ
+        pitch_w = kwargs.pop("ray_pitch_w", None)  # width of the image whose pixel pitch these rays have (a crop: the full image)
         if packed is None:
             with (torch.enable_grad() if grad_on else torch.no_grad()):
                 packed = ops.pack_planes(space_cache)
@@ -237,7 +238,8 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         sw, fw = self.geometry.mlp_weights()
         rc = self._render_config()
         if importance_sampled:  # consecutive samples crowd into the same texels: 2x2-pixel x 8-sample tiles
-            rc.tile_sb = int(tile_sb) if tile_sb is not None else self._tile_sb_for(rays_o.shape[2], space_cache.shape[-1])
+            rc.tile_sb = int(tile_sb) if tile_sb is not None else self._tile_sb_for(
+                int(pitch_w) if pitch_w else rays_o.shape[2], space_cache.shape[-1])
         ctx = torch.enable_grad() if grad_on else torch.no_grad()
         with ctx:
             out = functional.volume_render(space_cache, sw, fw, rays_o, rays_d, t_starts, t_ends, bg_color,
@@ -257,7 +259,11 @@ class GenerativeSpaceSDFVolumeRenderer(BaseModule):
         ms per step; training shapes (42^2 + 40^2 rays) 9.0 / 8.8 / 8.8 / 8.9 (tools/time_training_shapes.py)."""
         if self.tile_sb_importance is not None:
             return int(self.tile_sb_importance)
-        return 2 if image_w >= plane_w else 8
+        # pixel pitch in texels.  Round 6 (dense-rank scatter, 128 distinct texels per plane-tile): swept again at the
+        # training shapes, global render (pitch 6) x patch (a crop of the full-resolution image: pitch 2) -- 8 / 4 is the
+        # best pair (8.48 ms against 8.66 for 8 / 8 and 8.62 for 4 / 4; profiles/r06_tile_sb_sweep.txt)
+        pitch = plane_w / max(image_w, 1)
+        return 2 if pitch <= 1.0 else (4 if pitch <= 3.0 else 8)
 
     def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False) -> None:
         self._inv_std_cache = (None, None)  # one read-back per step at most; also catches `.data` writes
@@ -312,8 +318,9 @@ class PatchRenderer(BaseModule):
         ds = self.cfg.global_downsample
         g_o = F.interpolate(rays_o.permute(0, 3, 1, 2), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
         g_d = F.interpolate(rays_d.permute(0, 3, 1, 2), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
-        kw_g = kwargs if self.tile_sb_global is None else dict(kwargs, tile_sb=self.tile_sb_global)
-        kw_p = kwargs if self.tile_sb_patch is None else dict(kwargs, tile_sb=self.tile_sb_patch)
+        # (performance hints only: the patch is a crop of the full-resolution image, its rays keep that image's pixel pitch)
+        kw_g = dict(kwargs, ray_pitch_w=W // ds) if self.tile_sb_global is None else dict(kwargs, tile_sb=self.tile_sb_global)
+        kw_p = dict(kwargs, ray_pitch_w=W) if self.tile_sb_patch is None else dict(kwargs, tile_sb=self.tile_sb_patch)
         out_global = self.base_renderer(g_o.contiguous(), g_d.contiguous(), light_positions, bg_color, **kw_g)
         PS = self.cfg.patch_size
         px = torch.randint(0, W - PS, (1,)).item()
