@@ -730,7 +730,33 @@ def run_config2(args, device, rank, world, dist):
         cb["sample"] += "; stand-in for configs[2]: the same oracle pass with 193 (uniform) samples per ray -- the CPU cost per ray " \
                         "does not depend on where the samples sit"
         line["cpu_baseline"] = cb
-    print(json.dumps(line), flush=True)
+    emit(line)
+
+
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """stdout carries EXACTLY one JSON line.  Native libraries (gloo's `[Gloo] Rank ...`, RCCL's NCCL_DEBUG output, the HIP
+    runtime) write to file descriptor 1 behind Python's back, so the descriptor itself is re-pointed: a private duplicate of
+    the original stdout is kept for the result line, fd 1 becomes stderr for everything else in this process and its
+    children (the spawned ranks do the same, so only rank 0's line reaches the caller's stdout)."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.set_inheritable(_RESULT_FD, False)
+        os.dup2(2, 1)
+        sys.stdout = sys.stderr
+
+
+def emit(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
 
 
 def _free_port():
@@ -748,6 +774,7 @@ def spawn_ranks(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    # the ranks inherit THIS process's original stdout (claim_stdout() has not run here): each re-points its own fd 1
     return subprocess.call(cmd, env=env)
 
 
@@ -784,6 +811,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
         sys.exit(spawn_ranks(args))
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -933,6 +961,8 @@ def main():
                                       "uuid": str(getattr(props, "uuid", ""))})
         ranks_seen = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": info,
                       "distinct_devices": len({(i["uuid"], i["device"]) for i in info})}
+        if ranks_seen["world_size"] != args.gpus or len(info) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {ranks_seen['world_size']} ranks")
         if backend == "nccl" and ranks_seen["distinct_devices"] < world:
             # a mis-bound launch (two ranks on one GPU) must not print a scaling point
             raise SystemExit(f"bench.py: {world} ranks but only {ranks_seen['distinct_devices']} distinct GPUs: {info}")
@@ -1085,7 +1115,7 @@ def main():
                 line["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -149,7 +149,10 @@ def test_bench_spawns_its_own_ranks():
         r = subprocess.run(cmd, env=dict(env, TT_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, (r.returncode, r.stderr[-2000:])
-    d = json.loads(lines[-1])
+    # stdout is EXACTLY one JSON line: `[Gloo] Rank ...` / RCCL chatter of the native libraries goes to stderr
+    # (bench.py: claim_stdout re-points file descriptor 1 in every rank)
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{") and r.stdout.endswith("}\n"), r.stdout[:400]
+    d = json.loads(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2"
     mg = d["multi_gpu"]
     assert len(mg["per_rank_ms_per_step"]) == 2 and mg["rccl"]["world_size"] == 2 and mg["allreduce_bytes"] == 16640 * 4

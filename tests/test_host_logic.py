@@ -381,3 +381,20 @@ def test_concurrent_builds_are_serialised(tmp_path):
         for f in (out_path, os.path.join(os.path.dirname(out_path), "build", os.path.basename(out_path) + ".lock")):
             if os.path.exists(f):
                 os.unlink(f)
+
+
+def test_bench_stdout_is_one_json_line():
+    """bench.py: claim_stdout() re-points file descriptor 1 to stderr and keeps a private duplicate for the result line, so
+    whatever native libraries write to fd 1 (`[Gloo] Rank ...`, RCCL debug output) cannot reach the caller's stdout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); "
+            "os.write(1, b'[Gloo] Rank 0 is connected to 1 peer ranks\\n'); print('python-level chatter'); "
+            "os.system('echo from a child process'); bench.emit({'metric': 'm', 'value': 1.5})" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("\n") == 1 and json.loads(r.stdout) == {"metric": "m", "value": 1.5}, r.stdout
+    for s in ("[Gloo] Rank 0", "python-level chatter", "from a child process"):
+        assert s in r.stderr
