@@ -64,6 +64,14 @@ ALG = {
         "macs": {"f16x3": 4096 + 6144, "f16x4": 4096 + 6144, "valu": 384},
     },
 }
+ALG_POINTS = {  # --config 4: the per-point queries of the text -> mesh path (no backward)
+    "tt_query_field": {  # k_query_field: sdf net 32-64-64-1 + deformation head 32-64-64-3 on the 3 geometry planes
+        "device_kernel": "k_query_field", "bytes_8d": 3 * 4 * 32 * 4,
+        "macs": {"f16x3": 2 * (2048 + 4096), "valu": 64 + 192}},
+    "tt_query_points": {  # k_query_points<no normal, features>: sdf net + feature net 96-64-64-3 on all 6 planes
+        "device_kernel": "k_query_points", "bytes_8d": 6 * 4 * 32 * 4,
+        "macs": {"f16x3": 2048 + 4096 + 6144 + 4096, "valu": 64 + 192}},
+}
 BYTES_MARCH_FWD = 44        # t_starts, t_ends, sdf, sdf_grad(3), features(3) read; weights, trans written
 BYTES_MARCH_BWD = 68        # the 9 above + trans + g_sdf_grad(3) read; (d sdf, d sdf_grad) float4 written
 PEAK_F32_TFLOPS = 157.3     # dense fp32-input MFMA = fp32 vector peak (MI355X_MICROARCH.md): SURVEY 8(d)'s MLP roofline
@@ -71,6 +79,15 @@ PEAK_F16_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
 PEAK = {"f32": PEAK_F32_TFLOPS, "valu": PEAK_F32_TFLOPS, "f16x3": PEAK_F16_TFLOPS / 3.0, "f16x4": PEAK_F16_TFLOPS / 4.0,
         "f16x6": PEAK_F16_TFLOPS / 6.0}
 PEAK_HBM_GBS = 8000.0
+# the gather path: every 8-lane group of a decode wave requests one whole 128-byte texel line ("Coalesced
+# gathers"), served by the CU's vector L1 (TCP) and the XCD's L2 (TCC) -- the planes are cache-resident, HBM sees a fraction.
+# Peaks: L2 aggregate 34.5 TB/s (MI355X_MICROARCH.md, measured; 36.9 with L1 reuse), TCP 64 B/clk/CU x 256 CUs x 2.4 GHz
+PEAK_L2_GBS = 34500.0
+PEAK_TCP_GBS = 64.0 * 256 * 2.4
+# texel-line bytes a kernel REQUESTS per sample: the forward-shaped kernels read every corner once (= bytes_8d); a backward
+# kernel re-gathers its three planes (1536 B) and returns 1536 B of gradient lines through the atomic path
+GATHER_BYTES = {"tt_render_fwd": 3072, "tt_render_bwd_geo": 1536, "tt_render_bwd_tex": 1536, "tt_decode_rays": 1536,
+                "tt_query_field": 1536, "tt_query_points": 3072}
 # precision modes of the MLP products (include/tt_abi.h): the arithmetic type the path computes in
 DTYPES = {
     "split3": "f32 (fp32-grade: exact 3-piece fp16 operand split, 6 x v_mfma_f32_32x32x16_f16 per k-step, fp32 accumulation)",
@@ -98,7 +115,7 @@ def kernel_roofline(name, ms, n_samples, prec, wgrad_f32=False, work=None):
                     planes are cache-resident (no HBM traffic per texel) and the products run on the fp16 pipe.
       frac_pipe_mix the same with every FLOP priced on the pipe that executes it (split-fp16 products: 2500/3 TFLOP/s).
     """
-    a = ALG[name]
+    a = ALG[name] if name in ALG else ALG_POINTS[name]
     macs = {"f16x3": 0, "f16x4": 0, "f16x6": 0, "f32": 0, "valu": 0, **a["macs"]}
     if prec is True or prec == "f32":  # every matrix product on the fp32 MFMA
         macs = {"f16x3": 0, "f16x4": 0, "f32": macs["f16x3"] + macs["f16x4"] + macs["f32"], "valu": macs["valu"]}
@@ -112,18 +129,37 @@ def kernel_roofline(name, ms, n_samples, prec, wgrad_f32=False, work=None):
     t_f32 = flop / (PEAK_F32_TFLOPS * 1e12) * 1e3                                         # ms at 157.3 TFLOP/s
     t_mix = sum(2.0 * m * n_samples / (PEAK[p] * 1e12) for p, m in macs.items()) * 1e3    # ms at each pipe's peak
     extra = {}
+    gb = GATHER_BYTES.get(name)
+    if gb:
+        inb_g = work["inbounds_plane_frac"] if work is not None else 1.0
+        req = gb * n_samples * inb_g
+        t_l2 = req / (PEAK_L2_GBS * 1e9) * 1e3
+        live_g = work["live_tile_frac"] if work is not None else 1.0
+        extra["gather"] = {
+            "line_bytes_requested": int(req), "requested_GBs": round(req / (ms * 1e-3) / 1e9, 1),
+            "peak_l2_GBs": PEAK_L2_GBS, "frac_l2": round(t_l2 / ms, 4), "frac_tcp": round(req / (PEAK_TCP_GBS * 1e9) * 1e3 / ms, 4),
+            "note": "texel lines requested (128 B per in-bounds corner, x inbounds_plane_frac when counted) / duration against "
+                    "the aggregate L2 peak (34.5 TB/s) and the L1 (TCP) peak (64 B/clk/CU): the cache path the gathers really use"}
+        # the bound that can actually bind a cache-resident decode: its matrix-pipe time on the pipe it runs on, or its gather
+        # path -- never above 1 (unlike frac_8d, which prices cache-served bytes against HBM and fp16-pipe FLOPs at fp32 rate)
+        extra["frac_real"] = None  # filled below once t_mix is known
+        extra["_t_l2"], extra["_live"] = t_l2, live_g
     if work is not None:
         # what the kernel EXECUTED (device counters, tt_render_cfg.stats): a 32-sample tile step without an in-bounds
         # texel (and, in the backward, without a non-zero upstream gradient) is skipped exactly -- its FLOPs are not
         # done; a (plane, sample) pair outside the plane touches no texel -- its bytes are not moved
         live, inb = work["live_tile_frac"], work["inbounds_plane_frac"]
-        extra = {"live_tile_frac": round(live, 4), "inbounds_plane_frac": round(inb, 4),
+        extra.update({"live_tile_frac": round(live, 4), "inbounds_plane_frac": round(inb, 4),
                  "tile_steps_visited": work["visited"], "tile_steps_executed": work["executed"],
                  "executed_tflops": round(flop * live / (ms * 1e-3) / 1e12, 2),
                  "executed_GBs": round(a["bytes_8d"] * n_samples * inb / (ms * 1e-3) / 1e9, 1),
                  "frac_8d_executed": round(max(t_hbm * inb, t_f32 * live) / ms, 4),
                  "frac_pipe_mix_executed": round(max(t_hbm * inb, t_mix * live) / ms, 4),
-                 "ns_per_executed_tile_step": round(ms * 1e6 / max(work["executed"], 1), 3)}
+                 "ns_per_executed_tile_step": round(ms * 1e6 / max(work["executed"], 1), 3)})
+    if "_t_l2" in extra:
+        t_l2, live_g = extra.pop("_t_l2"), extra.pop("_live")
+        extra["frac_real"] = round(max(t_l2, t_mix * live_g) / ms, 4)
+        extra["bound_real"] = "l2-gather" if t_l2 >= t_mix * live_g else "matrix pipe (as executed)"
     return {
         **extra,
         "avg_ms": round(ms, 4), "alg_bytes_per_sample": a["bytes_8d"], "alg_flop_per_sample": int(flop_per_sample),
@@ -733,6 +769,149 @@ def run_config2(args, device, rank, world, dist):
     emit(line)
 
 
+def cpu_baseline_points(n_sample=262144, budget_s=20.0):
+    """--config 4: the CPU oracle's per-point decode (oracle/cpu_ref.py: geometry_forward + the deformation head through
+    vanilla_mlp) timed on `n_sample` points of the 160^3 grid plus the same number of colour queries; thread count calibrated
+    like cpu_baseline."""
+    from oracle import cpu_ref as O
+    host_cores = os.cpu_count() or 1
+    g = torch.Generator().manual_seed(0)
+    cache = torch.randn(1, 6, 32, 256, 256, generator=g) * 0.5
+    sw = O.init_mlp_weights([32, 64, 64, 1], g)
+    fw = O.init_mlp_weights([96, 64, 64, 3], g)
+    dw = O.init_mlp_weights([32, 64, 64, 3], g)
+    pts = torch.rand(1, n_sample, 3, generator=g) * 2 - 1
+
+    def step():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = O.geometry_forward(pts, cache, sw, fw, output_normal=False)   # sdf + colours (forward_field's sdf, export)
+            O.vanilla_mlp(out["enc_geo"], dw)                                   # the deformation head
+        return time.perf_counter() - t0
+
+    t_begin = time.perf_counter()
+    best_t, best_n = None, None
+    for nt in sorted({n for n in (4, 8, 16, 32) if n <= host_cores} | {min(host_cores, 8)}):
+        torch.set_num_threads(nt)
+        step()
+        dt = step()
+        if best_t is None or dt < best_t:
+            best_t, best_n = dt, nt
+        if time.perf_counter() - t_begin > budget_s * 0.5:
+            break
+    torch.set_num_threads(best_n)
+    times = [best_t]
+    while time.perf_counter() - t_begin < budget_s * 0.8 and len(times) < 7:
+        times.append(step())
+    dt = sorted(times)[len(times) // 2]
+    return {"value": n_sample / dt, "unit": "points/s", "cores": best_n, "kind": "port",
+            "sample": f"{n_sample} uniform points of the [-1,1]^3 box (of 4 096 000 + 300 000): sdf + deformation + colour of each "
+                      f"(a superset of the per-point work of the step: every point gets all three heads), fp32 torch CPU oracle, "
+                      f"median {dt:.3f} s/pass, {best_n} threads (best of a calibration over 4..32; host has {host_cores} cores)"}
+
+
+def run_config4(args, device):
+    """BASELINE configs[4] (text -> mesh): the HIP share of the export path, everything between the generator's triplane and
+    marching cubes / the OBJ writer.  One step = what `isosurface` + `colorize_mesh` ask of the geometry
+    (triplaneturbo_executable/utils/mesh_exporter.py:78-105, :143-183; few_step_triplane_dual_stable_diffusion.py:375-430):
+      geometry.forward_field(grid 160^3 in [-1,1]^3, space_cache)  -> sdf + deformation   (tt_planes_pack + tt_query_field)
+      geometry.export(300 000 vertices, space_cache)["features"]   -> vertex colours      (tt_planes_pack + tt_query_points)
+    through the plugin (registry name, isosurface_deformable_grid = True), one prompt, planes (1,6,32,256,256), N = 1 only."""
+    import triplaneturbo_amd as tt
+    from triplaneturbo_amd import ops
+    RES, N_V, R = 160, 300_000, 256
+    torch.manual_seed(0)
+    geo = tt.find("few-step-triplane-dual-stable-diffusion")({"isosurface_deformable_grid": True}).to(device)
+    geo.precision = args.precision
+    gen = torch.Generator().manual_seed(0)
+    cache = (torch.randn(1, 6, 32, R, R, generator=gen) * 0.5).to(device)
+    lin = torch.linspace(-1.0, 1.0, RES, device=device)
+    grid = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(1, -1, 3).contiguous()
+    # vertices of a mesh-like point set: a noisy sphere shell of radius ~0.5 (where the sdf's level set is, sphere bias 0.5)
+    v = torch.nn.functional.normalize(torch.randn(N_V, 3, generator=gen), dim=-1) * (0.5 + 0.05 * torch.randn(N_V, 1, generator=gen))
+    verts = v.to(device).reshape(1, N_V, 3).contiguous()
+
+    def step():
+        with torch.no_grad():
+            sdf, deform = geo.forward_field(grid, cache)
+            col = geo.export(verts, cache)["features"]
+        return sdf, deform, col
+
+    for _ in range(args.warmup):
+        out = step()
+    if args.pmc_child:
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        return
+    timer = ops.KernelTimer()
+    ops.set_kernel_timer(timer)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        out = step()
+        b.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    sdf, deform, col = out
+    assert sdf.shape == (1, RES ** 3, 1) and deform.shape == (1, RES ** 3, 3) and col.shape == (1, N_V, 3)
+    n_pts = {"tt_query_field": RES ** 3, "tt_query_points": N_V}
+    ksum = timer.summary(median=True)
+    kernels = {k: dict(kernel_roofline(k, ms, n_pts[k], args.precision), launches=n, points_per_launch=n_pts[k],
+                       points_per_s=round(n_pts[k] / (ms * 1e-3), 1))
+               for k, (ms, n) in ksum.items() if k in n_pts}
+    traffic, traffic_err = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_traffic(4, args.precision)
+    pipes, pipes_err = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_pipes(4, args.precision)
+    for k, vv in kernels.items():
+        dk = ALG_POINTS[k]["device_kernel"]
+        if traffic and dk in traffic:
+            vv["pmc"] = dict(traffic[dk], kernel=dk)
+        if pipes and dk in pipes:
+            vv["sq"] = dict(pipes[dk], kernel=dk)
+    dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+    kd = kernels[dom]
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": kd["alg_tflops"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": kd["frac_8d"], "definition": "frac_8d (SURVEY 8(d)'s fp32-MFMA roofline, as in --config 1)",
+                "frac_pipe_mix": kd["frac_pipe_mix"], "frac_real": kd.get("frac_real"), "bound_real": kd.get("bound_real"),
+                "gather": kd.get("gather"), "avg_kernel_ms": kd["avg_ms"],
+                "mfma_util": (kd.get("sq") or {}).get("mfma_util"), "valu_util": (kd.get("sq") or {}).get("valu_util"),
+                "waves_per_simd": (kd.get("sq") or {}).get("waves_per_simd"),
+                "traffic": (kd.get("pmc") or {}).get("bytes"),
+                "traffic_source": ("two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this script in this run"
+                                   if traffic else f"not collected: {traffic_err}"),
+                "note": "a forward-only decode over cache-resident planes: frac prices its algorithmic FLOPs at the fp32-MFMA "
+                        "peak (SURVEY 8d); frac_real = max(six-term fp16-pipe time, texel-line requests / L2 peak) / duration "
+                        "is the bound it can physically reach; gather = the L1/L2 path of its texel reads"}
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    ms = dt / args.steps * 1e3
+    n_total = RES ** 3 + N_V
+    line = {"metric": "HIP share of text->mesh export (BASELINE configs[4]): field query 160^3 + deformation head + 300 k vertex "
+                      "colours, decoded points/sec",
+            "value": n_total * args.steps / dt, "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "ms_per_step_median_hipevent": round(statistics.median(step_ms), 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPES[args.precision], "precision": args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4], HIP share: geometry.forward_field on the 160^3 isosurface grid (sdf + "
+                                   "deformation head) + geometry.export vertex colours for 300 000 vertices, planes "
+                                   "(1,6,32,256,256), forward only (mesh_exporter.py:78-105,143-183); marching cubes, the SD "
+                                   "generator and file output are not part of the path",
+                       "grid_points": RES ** 3, "vertices": N_V, "parallelism": "dp1",
+                       "latency_ms": {"forward_field": round(sum(kernels[k]["avg_ms"] for k in kernels if k == "tt_query_field"), 4),
+                                      "export_colours": round(sum(kernels[k]["avg_ms"] for k in kernels if k == "tt_query_points"), 4),
+                                      "step_wall": round(ms, 4)},
+                       "checksum": {"sdf_mean": float(sdf.mean()), "deform_abs_mean": float(deform.abs().mean()),
+                                    "colour_mean": float(col.mean())}},
+            "roofline": roofline, "kernels": kernels,
+            "glue_ms": round(statistics.median(step_ms) - sum(v_["avg_ms"] * v_["launches"] / args.steps for v_ in kernels.values()), 4),
+            "timed_region_s": round(dt, 3)}
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_points()
+    emit(line)
+
+
 _RESULT_FD = None
 
 
@@ -783,10 +962,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 300 = a ~2.7 s timed region; --config 2: 20)")
     ap.add_argument("--warmup", type=int, default=None, help="default 10 (--config 2: 2)")
-    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3),
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3, 4),
                     help="1 = BASELINE configs[1] per GPU (headline); 2 = configs[2]: the distillation loop's renders (8 prompts "
                          "x 4 views, PatchRenderer, 193 samples, 4 render+backward passes per step); 3 = configs[3]: 8 prompts x "
-                         "256x256 rays per GPU")
+                         "256x256 rays per GPU; 4 = configs[4]'s HIP share: field query 160^3 + deformation head + 300 k vertex "
+                         "colours (forward only, N = 1)")
     ap.add_argument("--precision", default="split3", choices=("split3", "f32", "split2"),
                     help="MLP products: split3 = fp32-grade 3-piece split on the fp16 pipe (default, the reference's "
                          "precision), f32 = fp32-input MFMA, split2 = the 2-piece fast mode of rounds 2-4")
@@ -805,7 +985,7 @@ def main():
     ap.add_argument("--grad-copies", type=int, default=1, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 20 if args.config == 2 else 300
+        args.steps = {2: 20, 4: 200}.get(args.config, 300)
     if args.warmup is None:
         args.warmup = 2 if args.config == 2 else 10
 
@@ -848,6 +1028,11 @@ def main():
 
     if args.exact_f32:
         args.precision = "f32"
+    if args.config == 4:
+        if world > 1:
+            raise SystemExit("--config 4 (export latency of one prompt) is an N = 1 workload")
+        run_config4(args, device)
+        return
     if args.config == 2:
         run_config2(args, device, rank, world, dist)
         if world > 1:

@@ -36,10 +36,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "training":
     kw = dict(space_cache=cache, text_embed=torch.zeros(2, 77, 1024), camera_distances=cd.to(dev), c2w=c2w.to(dev))
     ro, rd, bgc = ro.to(dev), rd.to(dev), torch.ones(3, device=dev)
 
+    # TT_LOSS_KEYS / TT_LOSS_SCALE: seeded projections of those outputs (bench.py --config 2's loss) instead of comp_rgb.mean()
+    _keys = [k for k in os.environ.get("TT_LOSS_KEYS", "").split(",") if k]
+    _scale = float(os.environ.get("TT_LOSS_SCALE", "1"))
+    _gen = torch.Generator().manual_seed(5)
+    _proj = {k: torch.randn(8, 128, 128, {"comp_rgb": 3, "opacity": 1, "depth": 1, "comp_normal_cam_vis": 3}[k],
+                            generator=_gen).to(dev) * _scale for k in _keys}
+
     def step():
         out = rend(ro, rd, None, bgc, **kw)
-        loss = out["comp_rgb"].mean() + (out["opacity"] ** 2 + 0.01).sqrt().mean() + \
-            ((out["sdf_grad"].norm(dim=-1) - 1) ** 2).mean()
+        loss = (sum((out[k] * v).sum() for k, v in _proj.items()) if _keys else out["comp_rgb"].mean()) + \
+            (out["opacity"] ** 2 + 0.01).sqrt().mean() + ((out["sdf_grad"].norm(dim=-1) - 1) ** 2).mean()
         for p_ in [cache] + list(geo.parameters()):
             p_.grad = None
         loss.backward()

@@ -55,10 +55,18 @@ ro, rd = ro.to(dev), rd.to(dev)
 bg = torch.ones(3, device=dev)
 
 
+# TT_LOSS_KEYS="comp_rgb,opacity,depth,comp_normal_cam_vis": seeded projections of those outputs (bench.py --config 2's loss)
+# instead of comp_rgb.mean(); the sparsity and eikonal terms stay
+_keys = [k for k in os.environ.get("TT_LOSS_KEYS", "").split(",") if k]
+_gen = torch.Generator().manual_seed(5)
+_proj = {k: torch.randn(P * NV, 128, 128, {"comp_rgb": 3, "opacity": 1, "depth": 1, "comp_normal_cam_vis": 3}[k],
+                        generator=_gen).to(dev) * float(os.environ.get("TT_LOSS_SCALE", "1")) for k in _keys}
+
+
 def step():
     out = r(ro, rd, None, bg, **kw)
-    loss = out["comp_rgb"].mean() + (out["opacity"] ** 2 + 0.01).sqrt().mean() + \
-        ((out["sdf_grad"].norm(dim=-1) - 1) ** 2).mean()
+    loss = (sum((out[k] * v).sum() for k, v in _proj.items()) if _keys else out["comp_rgb"].mean()) + \
+        (out["opacity"] ** 2 + 0.01).sqrt().mean() + ((out["sdf_grad"].norm(dim=-1) - 1) ** 2).mean()
     for p_ in [cache] + list(g.parameters()):
         p_.grad = None
     loss.backward()

@@ -609,67 +609,109 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
         dc.ju = 0.5f * cfg.plane_w / cfg.radius;
         dc.jv = 0.5f * cfg.plane_h / cfg.radius;
         dc.dbg = 0;
-        const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
-        const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
-        float T = 1.f, op = 0.f, dep = 0.f, wt2 = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+        // Register budget (two waves per SIMD = 256 registers, the decode peaks at ~250): what must survive a decode is kept
+        // small.  (i) The ray's origin / direction are re-read from memory every step (24 B per lane out of L1: the loads a
+        // spill would issue anyway, minus the scratch).  (ii) Both half-waves carry the same ray (lane i and i + 32), so the
+        // nine accumulators are split between them: half 0 owns opacity, depth, sum w t^2, n.x, n.y, half 1 owns r, g, b,
+        // n.z -- five registers (acc[k] += w * (hi ? B_k : A_k)) instead of nine; T is needed by both.
+        float T = 1.f, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
+        const float hif = (float)hi, lof = 1.f - hif;
 #pragma nounroll
         for (int si = 0; si < S; ++si) {
-            const long long sidx = ray * S + si;
-            const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
-            float tm, px, py, pz;
-            sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
+            float tm, px, py, pz, cosv, ux, uy, uz, sdf, dt;
+            {
+                long long rr = ray;
+                asm volatile("" : "+v"(rr));  // (opaque: the addresses and the loads stay inside the loop)
+                const float* ro = p.rays_o + rr * 3;
+                const float* rd = p.rays_d + rr * 3;
+                const float ts = p.t_starts[rr * S + si], te = p.t_ends[rr * S + si];
+                const float ox = ro[0], oy = ro[1], oz = ro[2];
+                const float dx = rd[0], dy = rd[1], dz = rd[2];
+                sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
+            }
             const float X = scale_coord(px, dc.radius), Y = scale_coord(py, dc.radius), Z = scale_coord(pz, dc.radius);
             // live = ray_ok && !(T < eps_T) as a product of 0/1 factors, then ONE compare (eps_T = 0: always live)
             const float livef = ray_okf * (__builtin_fabsf(T) < p.eps_T ? 0.f : 1.f);
             const bool live = livef != 0.f;
-            float s0, gq[3];
-            decode_geo_fwd<true, PREC>(L, dc, X, Y, Z, live, i, hi, s0, gq);
-            ++n_geo;
-            float nrm;
-            const float sdf = s0 + sphere_bias(px, py, pz, cfg.sdf_bias_radius, nrm);
-            const float gx = gq[0] + px / nrm, gy = gq[1] + py / nrm, gz = gq[2] + pz / nrm;
-            const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps
-            const float ign = rcp_(gn);
-            const float ux = gx * ign, uy = gy * ign, uz = gz * ign;
-            const float cosv = dx * ux + dy * uy + dz * uz;
+            {
+                float s0, gq[3];
+                decode_geo_fwd<true, PREC>(L, dc, X, Y, Z, live, i, hi, s0, gq);
+                ++n_geo;
+                float nrm;
+                // (the position again from the re-read ray: identical arithmetic, identical bits)
+                long long rr = ray;
+                asm volatile("" : "+v"(rr));
+                const float* ro = p.rays_o + rr * 3;
+                const float* rd = p.rays_d + rr * 3;
+                const float ts = p.t_starts[rr * S + si], te = p.t_ends[rr * S + si];
+                dt = te - ts;
+                const float ox = ro[0], oy = ro[1], oz = ro[2];
+                const float dx = rd[0], dy = rd[1], dz = rd[2];
+                sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
+                sdf = s0 + sphere_bias(px, py, pz, cfg.sdf_bias_radius, nrm);
+                const float gx = gq[0] + px / nrm, gy = gq[1] + py / nrm, gz = gq[2] + pz / nrm;
+                const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps
+                const float ign = rcp_(gn);
+                ux = gx * ign, uy = gy * ign, uz = gz * ign;
+                cosv = dx * ux + dy * uy + dz * uz;
+            }
             // (select, not a product: a dead lane's alpha may be NaN -- it decodes nothing)
-            float alpha = (cfg.flags & TT_R_VOLSDF) ? volsdf_alpha_terms(sdf, te - ts, kstd).alpha
-                                                    : neus_alpha_terms(sdf, cosv, te - ts, kstd, cfg.cos_anneal_ratio).alpha;
+            float alpha = (cfg.flags & TT_R_VOLSDF) ? volsdf_alpha_terms(sdf, dt, kstd).alpha
+                                                    : neus_alpha_terms(sdf, cosv, dt, kstd, cfg.cos_anneal_ratio).alpha;
             if (!live) alpha = 0.f;
             const float wgt = alpha * T;
             T *= 1.f - alpha;
-            op += wgt;
-            dep = fmaf(wgt, tm, dep);
-            wt2 = fmaf(wgt * tm, tm, wt2);
-            nx = fmaf(wgt, ux, nx);
-            ny = fmaf(wgt, uy, ny);
-            nz = fmaf(wgt, uz, nz);
+            // half 0: opacity, depth, sum w t^2, n.x, n.y;  half 1: n.z now, the colours after the texture decode
+            acc0 = fmaf(wgt, lof, acc0);
+            acc1 = fmaf(wgt * lof, tm, acc1);
+            acc2 = fmaf(wgt * lof * tm, tm, acc2);
+            acc3 = fmaf(wgt, hi ? uz : ux, acc3);
+            acc4 = fmaf(wgt * lof, uy, acc4);
             // want_tex = live && wgt > eps_w: wgt = alpha T is exactly 0 on a dead lane (alpha = 0 above) and eps_w >= 0,
             // so the weight test alone decides (eps_w = 0: every sample with a non-zero weight)
             const bool want_tex = __builtin_fabsf(wgt) > p.eps_w;  // (|.|: VolSDF alphas are not clipped, T and the weights can change sign)
             if (__any(want_tex)) {
                 float c[3];
-                decode_tex_fwd<PREC>(L, dc, X, Y, Z, want_tex, i, hi, c);
+                if constexpr (PREC == PREC_F32) {
+                    // the fp32-MFMA instantiation needs 11 more registers: the plane coordinates are rebuilt from the re-read
+                    // ray as well (same arithmetic, same bits) instead of living across the geometry decode
+                    long long rr = ray;
+                    asm volatile("" : "+v"(rr));
+                    const float* ro = p.rays_o + rr * 3;
+                    const float* rd = p.rays_d + rr * 3;
+                    float tm2, qx, qy, qz;
+                    sample_position(ro[0], ro[1], ro[2], rd[0], rd[1], rd[2], p.t_starts[rr * S + si], p.t_ends[rr * S + si], tm2,
+                                    qx, qy, qz);
+                    decode_tex_fwd<PREC>(L, dc, scale_coord(qx, dc.radius), scale_coord(qy, dc.radius),
+                                         scale_coord(qz, dc.radius), want_tex, i, hi, c);
+                } else {
+                    decode_tex_fwd<PREC>(L, dc, X, Y, Z, want_tex, i, hi, c);
+                }
                 ++n_tex;
                 if (want_tex) {  // NoMaterial + sigmoid-mipnerf (no_material.py:41-54, ops.py:118-119)
-                    cr = fmaf(wgt, sigmoid_(c[0]) * 1.002f - 0.001f, cr);
-                    cg = fmaf(wgt, sigmoid_(c[1]) * 1.002f - 0.001f, cg);
-                    cb = fmaf(wgt, sigmoid_(c[2]) * 1.002f - 0.001f, cb);
+                    const float wh = wgt * hif;
+                    acc0 = fmaf(wh, sigmoid_(c[0]) * 1.002f - 0.001f, acc0);
+                    acc1 = fmaf(wh, sigmoid_(c[1]) * 1.002f - 0.001f, acc1);
+                    acc2 = fmaf(wh, sigmoid_(c[2]) * 1.002f - 0.001f, acc2);
                 }
             }
             if (p.eps_T > 0.f && !__any(ray_okf * (__builtin_fabsf(T) < p.eps_T ? 0.f : 1.f) != 0.f)) break;  // every ray is opaque
         }
-        if (ray_ok && hi == 0) {
-            p.opacity[ray] = op;
-            p.depth[ray] = dep;
-            p.rgb_fg[ray * 3 + 0] = cr;
-            p.rgb_fg[ray * 3 + 1] = cg;
-            p.rgb_fg[ray * 3 + 2] = cb;
-            // z_variance = sum w (t - D)^2 with D = sum w t  (renderer :424-431)  =  sum w t^2 - 2 D^2 + D^2 sum w
-            p.z_var[ray] = wt2 - 2.f * dep * dep + dep * dep * op;
-            p.nacc[ray * 3 + 0] = nx;
-            p.nacc[ray * 3 + 1] = ny;
-            p.nacc[ray * 3 + 2] = nz;
+        if (ray_ok) {
+            if (hi == 0) {
+                const float op = acc0, dep = acc1, wt2 = acc2;
+                p.opacity[ray] = op;
+                p.depth[ray] = dep;
+                // z_variance = sum w (t - D)^2 with D = sum w t  (renderer :424-431)  =  sum w t^2 - 2 D^2 + D^2 sum w
+                p.z_var[ray] = wt2 - 2.f * dep * dep + dep * dep * op;
+                p.nacc[ray * 3 + 0] = acc3;
+                p.nacc[ray * 3 + 1] = acc4;
+            } else {
+                p.rgb_fg[ray * 3 + 0] = acc0;
+                p.rgb_fg[ray * 3 + 1] = acc1;
+                p.rgb_fg[ray * 3 + 2] = acc2;
+                p.nacc[ray * 3 + 2] = acc3;
+            }
         }
     }
     if (p.stats && lane == 0) {

@@ -194,8 +194,9 @@ def query_points(packed: Tensor, sdf_w: Sequence[Tensor], feat_w: Optional[Seque
     feat = torch.empty((B * N, 3), device=dev, dtype=torch.float32) if need_features else None
     flags = (_lib.TT_Q_NORMAL if need_normal else 0) | (_lib.TT_Q_TEX if need_features else 0) | _lib.q_flag(
         _lib.resolve_precision(precision, exact_f32))
-    st = _lib.load().tt_query_points(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, views_per_prompt, H, W,
-                                     radius, sdf_bias_radius, flags, _ptr(sdf), _ptr(grad), _ptr(feat), _stream())
+    with _timed("tt_query_points"):
+        st = _lib.load().tt_query_points(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, views_per_prompt, H, W,
+                                         radius, sdf_bias_radius, flags, _ptr(sdf), _ptr(grad), _ptr(feat), _stream())
     _lib.check(st, "tt_query_points")
     return sdf, grad, feat
 
@@ -214,9 +215,10 @@ def query_field(packed: Tensor, sdf_w: Sequence[Tensor], deform_w: Sequence[Tens
     wst = _lib.MlpWeights(*[_ptr(t) for t in sw + dw])
     sdf = torch.empty((B * N, 1), device=points.device, dtype=torch.float32)
     deform = torch.empty((B * N, 3), device=points.device, dtype=torch.float32)
-    st = _lib.load().tt_query_field(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, views_per_prompt, H, W,
-                                    radius, sdf_bias_radius, _lib.q_flag(_lib.resolve_precision(precision, exact_f32)), _ptr(sdf),
-                                    _ptr(deform), _stream())
+    with _timed("tt_query_field"):
+        st = _lib.load().tt_query_field(_ptr(packed), ctypes.byref(wst), _ptr(points), B, N, P, views_per_prompt, H, W,
+                                        radius, sdf_bias_radius, _lib.q_flag(_lib.resolve_precision(precision, exact_f32)),
+                                        _ptr(sdf), _ptr(deform), _stream())
     _lib.check(st, "tt_query_field")
     return sdf, deform
 
