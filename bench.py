@@ -410,6 +410,26 @@ def pmc_lds(config, precision="split3"):
     return out, None
 
 
+CACHE_PASS = ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCP_TCC_READ_REQ_sum"]
+
+
+def pmc_cache(config, precision="split3"):
+    """What the L2 (TCC) saw per kernel launch, one more counter pass: requests, hits, misses, and the read requests the
+    vector L1s (TCP) sent down.  l2_hit_rate = TCC_HIT / (TCC_HIT + TCC_MISS) (MI355X_MICROARCH.md, L2).  The byte figures
+    assume the 128-byte request / line size of gfx950 and are labelled so."""
+    res, err = pmc_pass(CACHE_PASS, config, precision)
+    if res is None:
+        return None, err
+    out = {}
+    for k in res.get("TCC_REQ_sum", {}):
+        g = lambda c: res.get(c, {}).get(k, 0.0)
+        hit, miss = g("TCC_HIT_sum"), g("TCC_MISS_sum")
+        out[k] = {"tcc_requests": int(g("TCC_REQ_sum")), "tcc_hits": int(hit), "tcc_misses": int(miss),
+                  "l2_hit_rate": round(hit / max(hit + miss, 1.0), 4), "tcp_tcc_read_requests": int(g("TCP_TCC_READ_REQ_sum")),
+                  "l2_request_bytes_at_128B": int(g("TCC_REQ_sum") * 128)}
+    return out, None
+
+
 STAT_ROWS = {"tt_render_fwd": 0, "tt_render_bwd_geo": 1, "tt_render_bwd_tex": 2}
 
 
@@ -865,8 +885,12 @@ def run_config4(args, device):
                for k, (ms, n) in ksum.items() if k in n_pts}
     traffic, traffic_err = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_traffic(4, args.precision)
     pipes, pipes_err = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_pipes(4, args.precision)
+    cch, cch_err = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_cache(4, args.precision)
     for k, vv in kernels.items():
         dk = ALG_POINTS[k]["device_kernel"]
+        if cch and dk in cch:
+            vv["cache"] = dict(cch[dk], kernel=dk,
+                               l2_request_GBs_at_128B=round(cch[dk]["l2_request_bytes_at_128B"] / (vv["avg_ms"] * 1e-3) / 1e9, 1))
         if traffic and dk in traffic:
             vv["pmc"] = dict(traffic[dk], kernel=dk)
         if pipes and dk in pipes:
@@ -876,7 +900,7 @@ def run_config4(args, device):
     roofline = {"kernel": dom, "bound": "mfma", "achieved": kd["alg_tflops"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                 "frac": kd["frac_8d"], "definition": "frac_8d (SURVEY 8(d)'s fp32-MFMA roofline, as in --config 1)",
                 "frac_pipe_mix": kd["frac_pipe_mix"], "frac_real": kd.get("frac_real"), "bound_real": kd.get("bound_real"),
-                "gather": kd.get("gather"), "avg_kernel_ms": kd["avg_ms"],
+                "gather": kd.get("gather"), "cache": kd.get("cache"), "avg_kernel_ms": kd["avg_ms"],
                 "mfma_util": (kd.get("sq") or {}).get("mfma_util"), "valu_util": (kd.get("sq") or {}).get("valu_util"),
                 "waves_per_simd": (kd.get("sq") or {}).get("waves_per_simd"),
                 "traffic": (kd.get("pmc") or {}).get("bytes"),
@@ -1188,8 +1212,12 @@ def main():
         traffic, traffic_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_traffic(args.config, args.precision)
         pipes, pipes_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_pipes(args.config, args.precision)
         lds, lds_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_lds(args.config, args.precision)
+        cch, cch_err = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else pmc_cache(args.config, args.precision)
         for k, v in kernels.items():
             dk = ALG[k]["device_kernel"]
+            if cch and dk in cch:
+                v["cache"] = dict(cch[dk], kernel=dk,
+                                  l2_request_GBs_at_128B=round(cch[dk]["l2_request_bytes_at_128B"] / (v["avg_ms"] * 1e-3) / 1e9, 1))
             if traffic and dk in traffic:
                 v["pmc"] = dict(traffic[dk], kernel=dk)
             if pipes and dk in pipes:
@@ -1209,6 +1237,7 @@ def main():
             frac_executed=kd.get("frac_8d_executed"), frac_pipe_mix_executed=kd.get("frac_pipe_mix_executed"),
             mfma_util=(kd.get("sq") or {}).get("mfma_util"), valu_util=(kd.get("sq") or {}).get("valu_util"),
             waves_per_simd=(kd.get("sq") or {}).get("waves_per_simd"),
+            frac_real=kd.get("frac_real"), bound_real=kd.get("bound_real"), gather=kd.get("gather"), cache=kd.get("cache"),
             sq_source=("one rocprofv3 --pmc pass of SQ counters over this script in this run (bench.py: pmc_pipes); "
                        "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs) is the physical matrix-"
                        "pipe utilisation north_star's 40 % bar is about") if pipes else f"not collected: {pipes_err}",

@@ -1,6 +1,9 @@
 // tt_backward_tex.hip -- texture half of the fused render backward: feature net backward, dV1 / dV2 / dV3, scatter of
 // d/d planes 3..5 (k_decode_bwd_tex), and the per-point variant tt_points_bwd_tex.  See tt_backward.hip for the overview.
 #include "tt_backward_common.h"
+#ifndef TT_TEX_REREAD_RAY
+#define TT_TEX_REREAD_RAY 1
+#endif
 
 // =====================================================================================================
 // texture half
@@ -102,12 +105,19 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
       const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
       const int view = (int)(ray / cfg.rays_per_view);
       const size_t pofs = (size_t)(view / cfg.views_per_prompt) * plane_stride;
+#if TT_TEX_REREAD_RAY
+      // Per-ray constants (origin, direction, d loss / d rgb) are RE-READ at the top of every tile step instead of living in
+      // nine registers across the item: the same addresses for every step of an item (L1 hits, ~0.5 % of a step), and the
+      // registers the allocator would otherwise spill to scratch memory (4 in the default mode, 68 in the fp32-MFMA mode).
+      // The ray index is laundered through an empty asm so that hipcc cannot hoist the loads back out of the loop.
+#else
       const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
       const float dx = p.rays_d ? p.rays_d[ray * 3 + 0] : 0.f, dy = p.rays_d ? p.rays_d[ray * 3 + 1] : 0.f,
                   dz = p.rays_d ? p.rays_d[ray * 3 + 2] : 0.f;
       float grgb[3];
 #pragma unroll
       for (int o = 0; o < 3; ++o) grgb[o] = p.g_rgb ? p.g_rgb[ray * 3 + o] : 0.f;
+#endif
       const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
       TT_PHASE(19);
       // Per-step inputs (weight, features, interval, upstream) are PREFETCHED one tile step ahead: their loads are
@@ -138,6 +148,16 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_tex(BwdTexParams p) {
         const int si = sb0 + ks;
         const bool valid = ray_ok && si < s_end;
         const float vf = ray_okf * (si < s_end ? 1.f : 0.f);
+#if TT_TEX_REREAD_RAY
+        long long rr = ray;
+        asm volatile("" : "+v"(rr));
+        const float ox = p.rays_o[rr * 3 + 0], oy = p.rays_o[rr * 3 + 1], oz = p.rays_o[rr * 3 + 2];
+        const float dx = p.rays_d ? p.rays_d[rr * 3 + 0] : 0.f, dy = p.rays_d ? p.rays_d[rr * 3 + 1] : 0.f,
+                    dz = p.rays_d ? p.rays_d[rr * 3 + 2] : 0.f;
+        float grgb[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) grgb[o] = p.g_rgb ? p.g_rgb[rr * 3 + o] : 0.f;
+#endif
         // ---- upstream: cbar_o = shrink * w_i * g_rgb[ray,o] * 1.002 * s(1-s) + g_features ----
         float cb[3];
 #pragma unroll

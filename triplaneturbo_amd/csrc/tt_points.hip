@@ -65,6 +65,30 @@ struct PointsBwdXWaves {
     static constexpr int value = PREC == PREC_F32 ? 4 : 8;
 #endif
 };
+// The masked vectors a2 / k2 are built from f32x4 LDS loads, so hipcc carries them as <4 x float> values; the transposed
+// products then take the register PAIRS (0,2), (1,3) of each group (PAIR_TR, tt_mfma16.h) and the compiler lowers that
+// shuffle through a 12-byte stack slot per group -- 48 B of scratch per lane in the split modes (rounds 4-5).  An empty asm
+// per element (no instruction) makes them plain scalars again.
+template <int N>
+__device__ __forceinline__ void scalarize(float (&v)[N]) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) asm("" : "+v"(v[r]));
+}
+struct Axis3 {  // three per-axis accumulators addressed by a compile-time axis
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    template <int A>
+    __device__ __forceinline__ float& at() {
+        if constexpr (A == 0) return a0;
+        else if constexpr (A == 1) return a1;
+        else return a2;
+    }
+    template <int A>
+    __device__ __forceinline__ float get() const {
+        if constexpr (A == 0) return a0;
+        else if constexpr (A == 1) return a1;
+        else return a2;
+    }
+};
 template <int PREC>
 __global__ __launch_bounds__(64 * PointsBwdXWaves<PREC>::value, 1) void k_points_bwd_x(PointsBwdXParams p) {
     __shared__ __attribute__((aligned(16))) float L[PREC == PREC_S3 ? PX3_FLOATS : PX_FLOATS];
@@ -128,9 +152,11 @@ __global__ __launch_bounds__(64 * PointsBwdXWaves<PREC>::value, 1) void k_points
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) a2[4 * g + e2] = h2[4 * g + e2] > 0.f ? w3[e2] : 0.f;
                 }
+                scalarize(a2);
                 mvtx<PREC, 64, 64, 64>(L + PX_W2, L + PXLO_W2, 0, a2, a1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) a1[r] = h1[r] > 0.f ? a1[r] : 0.f;
+                scalarize(a1);
                 mvtx<PREC, 32, 64, 32>(L + PX_W1, L + PXLO_W1, 0, a1, q, i, hi);
             }
         }
@@ -154,9 +180,11 @@ __global__ __launch_bounds__(64 * PointsBwdXWaves<PREC>::value, 1) void k_points
                         k2[4 * g + e2] = k2[4 * g + e2] > 0.f ? t : 0.f;
                     }
                 }
+                scalarize(k2);
                 mvtx<PREC, 64, 64, 64>(L + PX_V2, L + PXLO_V2, 0, k2, kb1, i, hi);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) kb1[r] = k1[r] > 0.f ? kb1[r] : 0.f;
+                scalarize(kb1);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {  // ebar_p = (V1[:, 32p : 32p+32])^T k1bar
                     float ebp[16];
@@ -167,15 +195,18 @@ __global__ __launch_bounds__(64 * PointsBwdXWaves<PREC>::value, 1) void k_points
             }
         }
         // ---- pass 2: re-gather the texels and reduce them against q / ebar ----
-        float gx3[3] = {0.f, 0.f, 0.f};   // J^T q            (world x, y, z)
-        float hx3[3] = {0.f, 0.f, 0.f};   // d (gbar . J^T q) / dx
-        float ex3[3] = {0.f, 0.f, 0.f};   // Jtex^T ebar
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        // (three named scalars each, not float[3]: hipcc's SLP pass pairs neighbouring elements of a 3-array into <2 x float>
+        // operations and then keeps the array in scratch memory)
+        Axis3 gx3, hx3, ex3;  // J^T q (world x, y, z);  d (gbar . J^T q) / dx;  Jtex^T ebar
+        const Axis3 gg3 = {gg[0], gg[1], gg[2]};
+        // (one body per plane with the plane index a compile-time constant: the early exit of an empty plane would otherwise
+        // keep the loop rolled and the axis-indexed accumulators gx3[au] ... in scratch memory -- 48 B per lane until round 6)
+        auto plane_pass = [&](auto PLc) {
+            constexpr int pl = decltype(PLc)::value;
             Corners c;
             corners_setup(PLANE_U(pl, X, Y, Z), PLANE_V(pl, X, Y, Z), H, W, valid, c);
-            if (!__any(c.any)) continue;
-            const int au = pl == 2 ? 2 : 0, av = pl == 1 ? 2 : 1;  // world axis of the plane's u / v coordinate
+            if (!__any(c.any)) return;
+            constexpr int au = pl == 2 ? 2 : 0, av = pl == 1 ? 2 : 1;  // world axis of the plane's u / v coordinate
             float Gu = 0.f, Gv = 0.f, Sx = 0.f, Eu = 0.f, Ev = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -198,23 +229,25 @@ __global__ __launch_bounds__(64 * PointsBwdXWaves<PREC>::value, 1) void k_points
                     Ev = fmaf(c.dv[k], d, Ev);
                 }
             }
-            gx3[au] = fmaf(ju, Gu, gx3[au]);
-            gx3[av] = fmaf(jv, Gv, gx3[av]);
-            hx3[au] = fmaf(gg[av] * (ju * jv), Sx, hx3[au]);
-            hx3[av] = fmaf(gg[au] * (ju * jv), Sx, hx3[av]);
-            ex3[au] = fmaf(ju, Eu, ex3[au]);
-            ex3[av] = fmaf(jv, Ev, ex3[av]);
-        }
+            gx3.at<au>() = fmaf(ju, Gu, gx3.at<au>());
+            gx3.at<av>() = fmaf(jv, Gv, gx3.at<av>());
+            hx3.at<au>() = fmaf(gg3.get<av>() * (ju * jv), Sx, hx3.at<au>());
+            hx3.at<av>() = fmaf(gg3.get<au>() * (ju * jv), Sx, hx3.at<av>());
+            ex3.at<au>() = fmaf(ju, Eu, ex3.at<au>());
+            ex3.at<av>() = fmaf(jv, Ev, ex3.at<av>());
+        };
+        plane_pass(std::integral_constant<int, 0>{});
+        plane_pass(std::integral_constant<int, 1>{});
+        plane_pass(std::integral_constant<int, 2>{});
         // sphere bias |x| - r: gradient x / |x|, Hessian (I - xhat xhat^T) / |x|
         const float nrm = sqrtf((px * px + py * py) + pz * pz);
         const float inv = nrm > 0.f ? 1.f / nrm : 0.f;
-        const float xh[3] = {px * inv, py * inv, pz * inv};
-        const float xg = xh[0] * gg[0] + xh[1] * gg[1] + xh[2] * gg[2];
+        const float xh0 = px * inv, xh1 = py * inv, xh2 = pz * inv;
+        const float xg = xh0 * gg3.a0 + xh1 * gg3.a1 + xh2 * gg3.a2;
         if (valid && hi == 0) {
-#pragma unroll
-            for (int o = 0; o < 3; ++o)
-                p.grad_points[idx * 3 + o] =
-                    gs * (gx3[o] + xh[o]) + hx3[o] + (gg[o] - xh[o] * xg) * inv + ex3[o];
+            p.grad_points[idx * 3 + 0] = gs * (gx3.a0 + xh0) + hx3.a0 + (gg3.a0 - xh0 * xg) * inv + ex3.a0;
+            p.grad_points[idx * 3 + 1] = gs * (gx3.a1 + xh1) + hx3.a1 + (gg3.a1 - xh1 * xg) * inv + ex3.a1;
+            p.grad_points[idx * 3 + 2] = gs * (gx3.a2 + xh2) + hx3.a2 + (gg3.a2 - xh2 * xg) * inv + ex3.a2;
         }
     }
 }
