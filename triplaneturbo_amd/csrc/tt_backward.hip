@@ -11,6 +11,9 @@
 //
 // Everything per-sample is RECOMPUTED from the planes; the forward saves only trans / weights / features.
 #include "tt_backward_common.h"
+#ifndef TT_GEO_REREAD_RAY
+#define TT_GEO_REREAD_RAY 0
+#endif
 
 // =====================================================================================================
 // geometry half
@@ -142,10 +145,12 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
         const int ks = i % tg.sb;  // this lane's sample offset inside a tile step
         const int view = (int)(ray / cfg.rays_per_view);
         const size_t pofs = (size_t)(view / cfg.views_per_prompt) * plane_stride;
+#if !TT_GEO_REREAD_RAY
         const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
         // rays_d == null: explicit points (tt_points_bwd_*), x = rays_o exactly
         const float dx = p.rays_d ? p.rays_d[ray * 3 + 0] : 0.f, dy = p.rays_d ? p.rays_d[ray * 3 + 1] : 0.f,
                     dz = p.rays_d ? p.rays_d[ray * 3 + 2] : 0.f;
+#endif
         const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
         // per-step inputs are prefetched one tile step ahead (see k_decode_bwd_tex); a step past the chunk reads a
         // clamped, valid address
@@ -180,6 +185,14 @@ __global__ __launch_bounds__(256, 1) void k_decode_bwd_geo(BwdGeoParams p) {
                          cfg.skip_eps_geo)))
                 continue;
             float tm, px, py, pz;
+#if TT_GEO_REREAD_RAY
+            // (per-ray constants re-read per tile step, as in k_decode_bwd_tex: dev A/B, off by default)
+            long long rr = ray;
+            asm volatile("" : "+v"(rr));
+            const float ox = p.rays_o[rr * 3 + 0], oy = p.rays_o[rr * 3 + 1], oz = p.rays_o[rr * 3 + 2];
+            const float dx = p.rays_d ? p.rays_d[rr * 3 + 0] : 0.f, dy = p.rays_d ? p.rays_d[rr * 3 + 1] : 0.f,
+                        dz = p.rays_d ? p.rays_d[rr * 3 + 2] : 0.f;
+#endif
             sample_position(ox, oy, oz, dx, dy, dz, in.ts, in.te, tm, px, py, pz);
             const float X = scale_coord(px, cfg.radius), Y = scale_coord(py, cfg.radius),
                         Z = scale_coord(pz, cfg.radius);

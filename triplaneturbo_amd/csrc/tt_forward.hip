@@ -437,6 +437,9 @@ __global__ __launch_bounds__(64 * QueryFieldWaves<PREC>::value, PREC == PREC_S3 
 }
 
 // =====================================================================================================
+#ifndef TT_FWD_REREAD_RAY
+#define TT_FWD_REREAD_RAY 0
+#endif
 // K1: decode every sample of every ray (tiles of 32 adjacent rays x one sample index, chunks of CH indices)
 // =====================================================================================================
 struct DecodeRaysParams {
@@ -491,8 +494,10 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
         dc.ju = 0.5f * cfg.plane_w / cfg.radius;
         dc.jv = 0.5f * cfg.plane_h / cfg.radius;
         dc.dbg = cfg.flags;
+#if !TT_FWD_REREAD_RAY
         const float ox = p.rays_o[ray * 3 + 0], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
         const float dx = p.rays_d[ray * 3 + 0], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
+#endif
         const int s_end = (ck + 1) * tg.chunk < S ? (ck + 1) * tg.chunk : S;
 #if TT_FWD_PREFETCH
         // the sample interval of the NEXT tile step is loaded one step ahead (a step past the chunk reads a clamped, valid
@@ -521,7 +526,17 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
             const float ts = p.t_starts[sidx], te = p.t_ends[sidx];
 #endif
             float tm, px, py, pz;
+#if TT_FWD_REREAD_RAY
+            // (dev A/B, off by default: the ray re-read per tile step and the position rebuilt after the decode)
+            {
+                long long rr = ray;
+                asm volatile("" : "+v"(rr));
+                sample_position(p.rays_o[rr * 3 + 0], p.rays_o[rr * 3 + 1], p.rays_o[rr * 3 + 2], p.rays_d[rr * 3 + 0],
+                                p.rays_d[rr * 3 + 1], p.rays_d[rr * 3 + 2], ts, te, tm, px, py, pz);
+            }
+#else
             sample_position(ox, oy, oz, dx, dy, dz, ts, te, tm, px, py, pz);
+#endif
             float s0, gq[3], c[3];
             decode_fwd<NEED_N, NEED_TEX, PREC>(L, dc, px, py, pz, rvalid, i, hi, s0, gq, c);
             float nrm;
