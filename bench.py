@@ -57,11 +57,15 @@ ALG = {
         "device_kernel": "k_decode_bwd_geo",
         "bytes_8d": 3 * 4 * 32 * 4,
         "macs": {"f16x3": 2048 + 4096 + 4096 + 2048 + 2048 + 4096, "f16x4": 2048 + 4096, "valu": 256},
+        # executed on top of the algorithmic products: the scatter-combine GEMM (one 32-row x 32-sample x 32-channel tile per plane)
+        "macs_exec_extra": {"f16x3": 3 * 1024},
     },
     "tt_render_bwd_tex": {  # k_decode_bwd_tex: activations 10432 + weight gradients 10432
         "device_kernel": "k_decode_bwd_tex",
         "bytes_8d": 3 * 4 * 32 * 4,
         "macs": {"f16x3": 4096 + 6144, "f16x4": 4096 + 6144, "valu": 384},
+        # executed on top: the RECOMPUTE of k1 = V1 e, k2 = V2 k1 (mat-vec precision) and the scatter-combine GEMM
+        "macs_exec_extra": {"f16x3": 6144 + 4096, "scatter_f16x3": 3 * 1024},
     },
 }
 ALG_POINTS = {  # --config 4: the per-point queries of the text -> mesh path (no backward)
@@ -158,8 +162,18 @@ def kernel_roofline(name, ms, n_samples, prec, wgrad_f32=False, work=None):
                  "ns_per_executed_tile_step": round(ms * 1e6 / max(work["executed"], 1), 3)})
     if "_t_l2" in extra:
         t_l2, live_g = extra.pop("_t_l2"), extra.pop("_live")
-        extra["frac_real"] = round(max(t_l2, t_mix * live_g) / ms, 4)
-        extra["bound_real"] = "l2-gather" if t_l2 >= t_mix * live_g else "matrix pipe (as executed)"
+        # matrix-pipe time of what the kernel EXECUTES: the algorithmic products + the recomputed forward products and the
+        # scatter-combine GEMM of the backward kernels (not algorithmic work, but real pipe time)
+        t_extra = 0.0
+        for pk, m in a.get("macs_exec_extra", {}).items():
+            if pk == "scatter_f16x3" or (pk == "f16x3" and name == "tt_render_bwd_geo"):
+                pipe = "f32" if (prec is True or prec == "f32") else "f16x3"      # the combine GEMM: two-piece operands, fp32 in f32 mode
+            else:
+                pipe = "f32" if (prec is True or prec == "f32") else ("f16x6" if prec == "split3" else "f16x3")
+            t_extra += 2.0 * m * n_samples / (PEAK[pipe] * 1e12) * 1e3
+        extra["t_pipe_executed_ms"] = round((t_mix + t_extra) * live_g, 4)
+        extra["frac_real"] = round(max(t_l2, (t_mix + t_extra) * live_g) / ms, 4)
+        extra["bound_real"] = "l2-gather" if t_l2 >= (t_mix + t_extra) * live_g else "matrix pipe (as executed, incl. recompute + scatter GEMM)"
     return {
         **extra,
         "avg_ms": round(ms, 4), "alg_bytes_per_sample": a["bytes_8d"], "alg_flop_per_sample": int(flop_per_sample),
