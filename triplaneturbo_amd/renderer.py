@@ -316,8 +316,10 @@ class PatchRenderer(BaseModule):
             with (torch.enable_grad() if torch.is_grad_enabled() else torch.no_grad()):
                 kwargs["packed"] = ops.pack_planes(sc)
         ds = self.cfg.global_downsample
-        g_o = F.interpolate(rays_o.permute(0, 3, 1, 2), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
-        g_d = F.interpolate(rays_d.permute(0, 3, 1, 2), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
+        # (channels-first COPIES: ATen's bilinear kernel is ~10x slower on the permuted view -- 142 us per call at 32 views of
+        # 128 x 128, 1 % of a training-shape pass -- and computes the same values)
+        g_o = F.interpolate(rays_o.permute(0, 3, 1, 2).contiguous(), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
+        g_d = F.interpolate(rays_d.permute(0, 3, 1, 2).contiguous(), (H // ds, W // ds), mode="bilinear").permute(0, 2, 3, 1)
         # (performance hints only: the patch is a crop of the full-resolution image, its rays keep that image's pixel pitch)
         kw_g = dict(kwargs, ray_pitch_w=W // ds) if self.tile_sb_global is None else dict(kwargs, tile_sb=self.tile_sb_global)
         kw_p = dict(kwargs, ray_pitch_w=W) if self.tile_sb_patch is None else dict(kwargs, tile_sb=self.tile_sb_patch)
