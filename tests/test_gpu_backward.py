@@ -177,8 +177,9 @@ def test_every_tiling_matches_oracle(mods, chunk, blocked, sb, monkeypatch):
 
 @pytest.mark.parametrize("sb,copies,precision", [(1, 1, "split3"), (4, 3, "split3"), (32, 2, "split2"), (8, 1, "f32")])
 def test_sparse_rays_take_the_direct_scatter_path(mods, sb, copies, precision, monkeypatch):
-    """Rays several texels apart (9x6 rays over 128x128 planes): a tile's footprint is far wider than the 8x8 slot
-    window of the matrix-core combine, so most corner references lose their slot and go through the direct
+    """Rays several texels apart (9x6 rays over 128x128 planes): a tile's footprint is far wider than the texel table of
+    the matrix-core combine (16 x 16 torus since round 6, 8 x 8 slots before), so a plane-tile holds more than 64 distinct
+    texels (the second 64-row pass of scatter v2) and texels that collide in the table go through the direct
     half-wave-per-reference scatter.  Also covers privatised gradient copies (cfg.grad_copies > 1)."""
     ops, functional = mods
     P, R, n_view, Hh, Ww, S, seed = 1, 128, 2, 9, 6, 24, 33
