@@ -283,12 +283,29 @@ __device__ __forceinline__ void stage_decode_images(float* L, const MlpPtrs& w) 
 #define DECODE_THREADS 512
 #endif
 
+// Staggered wave priority (dev A/B, TT_PRIO_MODE; 0 = off): the two waves of a SIMD run the same phases (gather -> products -> ...)
+// and, arbitrated evenly, tend to stay in step -- both in their matrix phase, then both in their VALU phase -- so the pipes
+// alternate instead of overlapping.  A STATIC higher priority for one wave of each pair lets it run as if alone while the other
+// fills the slots it leaves.  Mode 1: waves 4..7 of the 8-wave workgroup (wave w sits on SIMD w % 4); mode 2: odd waves.
+#ifndef TT_PRIO_MODE
+#define TT_PRIO_MODE 0
+#endif
+__device__ __forceinline__ void tt_stagger_priority() {
+#if TT_PRIO_MODE == 1
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(3);
+#elif TT_PRIO_MODE == 2
+    if ((threadIdx.x >> 6) & 1) __builtin_amdgcn_s_setprio(3);
+#elif TT_PRIO_MODE == 3
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
+}
 template <bool NEED_N, bool NEED_TEX, int PREC>
 __global__ __launch_bounds__(DECODE_THREADS) void k_query_points(QueryParams p) {
     __shared__ __attribute__((aligned(16))) float L[FwdWFloats<PREC>::value + (DECODE_THREADS / 64) * GC_SCRATCH_FLOATS];
     float* T = L + FwdWFloats<PREC>::value + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
     stage_decode_images<NEED_N, NEED_TEX, PREC>(L, p.w);
     __syncthreads();
+    tt_stagger_priority();
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const long long tiles_per_batch = (p.n_points + TT_TILE - 1) / TT_TILE;
     const long long n_tiles = tiles_per_batch * p.n_batch;
@@ -388,6 +405,7 @@ __global__ __launch_bounds__(64 * QueryFieldWaves<PREC>::value, PREC == PREC_S3 
         lds_load_matrix(L + OFF_D3, w.v3, 3, 64, 64);
     }
     __syncthreads();
+    tt_stagger_priority();
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const long long tiles_per_batch = (p.n_points + TT_TILE - 1) / TT_TILE;
     const long long n_tiles = tiles_per_batch * p.n_batch;
@@ -464,6 +482,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_decode_rays(DecodeRaysParams
     float* T = L + FwdWFloats<PREC>::value + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
     stage_decode_images<NEED_N, NEED_TEX, PREC>(L, p.w);
     __syncthreads();
+    tt_stagger_priority();
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
@@ -596,6 +615,7 @@ __global__ __launch_bounds__(DECODE_THREADS) void k_render_eval(RenderEvalParams
     float* T = L + FwdWFloats<PREC>::value + (threadIdx.x >> 6) * GC_SCRATCH_FLOATS;
     stage_decode_images<true, true, PREC>(L, p.w);
     __syncthreads();
+    tt_stagger_priority();
     const tt_render_cfg& cfg = p.cfg;
     const TileGeom& tg = p.geom;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
