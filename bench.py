@@ -795,6 +795,11 @@ def run_config2(args, device, rank, world, dist):
             "roofline": roofline, "kernels": kernels,
             "other_entry_points_ms_per_step": {k: round(v, 4) for k, v in per_step.items() if k not in kernels},
             "glue_ms": round(ms - sum(per_step.values()), 3), "timed_region_s": round(dt, 3)}
+    if world > 1:
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        line["multi_gpu"] = {"rccl": {"backend": dist.get_backend(), "world_size": dist.get_world_size()},
+                             "note": "one flat all-reduce of the renderer-side MLP gradients per step (allreduce_mlp_grads)"}
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(S=193)
         cb["sample"] += "; stand-in for configs[2]: the same oracle pass with 193 (uniform) samples per ray -- the CPU cost per ray " \
