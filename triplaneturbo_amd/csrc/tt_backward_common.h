@@ -275,6 +275,8 @@ __device__ __forceinline__ void flush_wgrad_reduced(float* R, int& parity, const
     { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }
 
 // ---- plane-gradient scatter, combined on the matrix cores --------------------------------------------------
+// (The text below describes the idea and its ROUNDS 2-5 form, kept as -DTT_SCATTER_V1 for A/B builds; the product build
+// uses the round-6 form further down -- 16 x 16 texel table, dense ranks, short flush -- under "#else  // !TT_SCATTER_V1".)
 // fp32 global atomics are THE bottleneck of the backward on MI355X (~325 G atomic float-adds/s chip-wide,
 // pattern-independent; LDS fp32 atomics are even slower: one ds_add_f32 wave-instruction per ~190 cycles per CU,
 // both measured with tools/atomic_bench.hip / tools/lds_atomic_bench.hip).  A tile is 32 adjacent rays at one
